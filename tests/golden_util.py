@@ -1,0 +1,42 @@
+"""Loaders for the committed golden vectors (tests/golden/, made by make_golden.py
+from the real reference).  Data only; numpy.load with allow_pickle=False."""
+import json
+import os
+
+import numpy as np
+
+from checkers import BCH, REF_CODES, REF_VARIANTS
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = {0: "bch15_7", 1: "bch15_5", 4: "bch31_16", 5: "bch63_45", 6: "bch255_231", 8: "rs7_3", 9: "rs15_9",
+         10: "rs255_223", 11: "bch127_113", 13: "bch63_39"}
+SOFT_CIDS = (0, 4, 5, 6)
+HARD_CIDS = tuple(sorted(NAMES))
+RULES = {"o0": 0, "o1": 1, "o2": 2}
+
+
+def constants():
+    with open(os.path.join(GOLDEN, "constants.json")) as f:
+        return {int(k): v for k, v in json.load(f).items()}
+
+
+def exercises():
+    with open(os.path.join(GOLDEN, "exercises.json")) as f:
+        return json.load(f)
+
+
+def load(kind, cid):
+    return np.load(os.path.join(GOLDEN, "%s_%s.npz" % (kind, NAMES[cid])), allow_pickle=False)
+
+
+def minsum_cases(cid):
+    """Yields (variant_id, (oracle_variant, alpha, beta), rule_id, b, L, it, st) for one code."""
+    d = load("minsum", cid)
+    n = REF_CODES[cid]
+    for v in sorted(REF_VARIANTS):
+        for rule, rid in RULES.items():
+            key = "v%d_%s" % (v, rule)
+            width = d["y"].shape[1]
+            b = np.unpackbits(d[key + "_b"], axis=1)[:, :width]
+            yield v, REF_VARIANTS[v], rid, b, d[key + "_L"], d[key + "_it"].astype(np.uint32), d[key + "_st"].astype(
+                np.int32)

@@ -1,0 +1,102 @@
+"""Oracle (plain-C restatement) against the committed golden vectors, which hold
+the REAL reference's outputs (tests/golden/make_golden.py).  CPU only; this is
+the check that travels to the GPU box, where /root/reference does not exist.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+from checkers import BCH, BM, EUKLID, PGZ, REF_CODES, Oracle
+
+ALGS = ((PGZ, "pgz", "PGZ"), (BM, "bm", "BM"), (EUKLID, "euklid", "EUKLID"))
+
+
+def oracle_for(cid):
+    return Oracle(*REF_CODES[cid])
+
+
+def test_constants_app_d():
+    consts = G.constants()
+    for cid, c in consts.items():
+        o = oracle_for(cid)
+        assert (o.n, o.k, o.l, o.t, o.dmin) == (c["n"], c["k"], c["l"], c["t"], c["dmin"])
+        assert list(o.g) == c["g"] and list(o.h) == c["h"] and list(o.roots) == c["roots"]
+        H = o.H()
+        assert [j for j in range(o.n) if H[0, j]] == c["row0_support"]
+        for i in range(1, o.k):  # cyclic.h:353-356: row i = row 0 shifted right by i
+            assert np.array_equal(H[i, i:], H[0, : o.n - i]) and not H[i, :i].any()
+        for name, s in c["to_string"].items():
+            assert o.to_string(name) == s
+    # SURVEY App. D spot values
+    assert consts[0]["g"] == [1, 0, 0, 0, 1, 0, 1, 1, 1] and consts[0]["row0_support"] == [0, 1, 3, 7]
+    assert consts[6]["k"] == 24 and len(consts[6]["row0_support"]) == 112
+    assert consts[10]["to_string"]["BM"] == "(255, 223, 34)-BM"  # Q6
+
+
+def test_exercises_kat():
+    """src/exercises.c++ tasks 6.1-6.10."""
+    for case in G.exercises():
+        o = oracle_for(case["code"])
+        out, nerr, st, ub = o.correct_hard(case["alg"], np.array(case["rx"], np.uint8), case["erasures"])
+        assert (st[0] == 0) == (case["status"] == 0), case["task"]
+        if case["status"] == 0:
+            assert list(out[0]) == case["out"], case["task"]
+    by_task = {c["task"]: c for c in G.exercises()}
+    assert by_task["6.1 b1"]["out"] == [1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1]  # expect_equal(a, ...)
+    assert by_task["6.2"]["status"] == 1 and by_task["6.5"]["status"] == 1
+    assert by_task["6.9 bm"]["out"] == by_task["6.9 pgz"]["out"]
+
+
+@pytest.mark.parametrize("cid", G.HARD_CIDS)
+def test_encode_golden(cid):
+    d = G.load("encode", cid)
+    o = oracle_for(cid)
+    assert np.array_equal(o.encode(d["msg"]), d["cw"])
+
+
+@pytest.mark.parametrize("cid", G.HARD_CIDS)
+def test_hard_golden(cid):
+    d = G.load("hard", cid)
+    o = oracle_for(cid)
+    for alg, key, name in ALGS:
+        out, nerr, st, ub = o.correct_hard(alg, d["rx"])
+        r_st, r_out = d["status_" + key], d["out_" + key]
+        skip = d["notsolvable_" + key].copy()  # Q9 in rs::error_values
+        if alg == BM:
+            skip |= ub.astype(bool)  # F3
+        if alg == PGZ:
+            skip |= (r_st == 0) != (d["status_euklid"] == 0)  # Q9 in PGZ
+        keep = ~skip
+        assert keep.sum() >= 0.8 * len(keep)
+        assert np.array_equal((st == 0)[keep], (r_st == 0)[keep]), name
+        ok = keep & (st == 0)
+        assert np.array_equal(out[ok], r_out[ok]), name
+        # <= t errors always decode to the transmitted word
+        easy = keep & (d["nerr"] <= o.t)
+        assert (st[easy] == 0).all() and np.array_equal(out[easy], d["cw"][easy])
+        if alg != PGZ:
+            bad = keep & (st != 0)
+            assert np.array_equal(st[bad] == 3, d["recheck_" + key][bad]), name
+
+
+@pytest.mark.parametrize("cid", G.SOFT_CIDS)
+def test_minsum_golden(cid):
+    d = G.load("minsum", cid)
+    o = oracle_for(cid)
+    y, iters = d["y"], int(d["iterations"])
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in G.minsum_cases(cid):
+        b, L, it, st = o.minsum(ov, iters, y, alpha, beta, rule, fast=True)
+        assert np.array_equal(st != 0, gst != 0), (v, rule)
+        ok = st == 0
+        assert np.array_equal(b[ok], gb[ok]), (v, rule)
+        assert np.array_equal(it[ok], git[ok]), (v, rule)
+        assert np.allclose(L[ok], gL[ok], rtol=0, atol=1e-5), (v, rule)
+    # the faithful O(w^2) form on a subset (slow for n=255)
+    sub = slice(0, 8 if cid == 6 else 32)
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in G.minsum_cases(cid):
+        if cid == 6 and v not in (0, 2, 4):
+            continue
+        b, L, it, st = o.minsum(ov, iters, y[sub], alpha, beta, rule)
+        ok = st == 0
+        assert np.array_equal(st != 0, gst[sub] != 0)
+        assert np.array_equal(b[ok], gb[sub][ok]) and np.array_equal(L[ok], gL[sub][ok])
