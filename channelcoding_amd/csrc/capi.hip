@@ -1,0 +1,368 @@
+// capi.hip -- the extern "C" boundary of libchannelcoding_amd.so.
+// Every function mirrors a member of the reference's cyclic<>/primitive_bch/rs
+// API (see include/channelcoding_amd.h for the file:line map).  Host-pointer
+// entry points stage through device memory and call the _dev ones; there is no
+// CPU decode path in this library.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <vector>
+
+#include "cc_internal.hpp"
+
+namespace ccamd {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &s) { g_last_error = s; }
+int hip_fail(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return CC_ERR_HIP;
+}
+
+namespace {
+
+// binds the calling thread to the code's device for the duration of a call
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      switched = hipSetDevice(dev) == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 16); }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+bool is_soft(int alg) { return alg >= CC_ALG_MS && alg <= CC_ALG_2DNMS; }
+bool is_hard(int alg) { return alg >= CC_ALG_PGZ && alg <= CC_ALG_EUKLID; }
+
+const char *alg_name(int alg) {
+  switch (alg) {  // Algorithm::to_string(): hard_decision.h:15-24, soft_decision.h:20-73
+    case CC_ALG_PGZ: return "PGZ";
+    case CC_ALG_BM: return "BM";
+    case CC_ALG_EUKLID: return "EUKLID";
+    case CC_ALG_MS: return "MS";
+    case CC_ALG_NMS: return "NMS";
+    case CC_ALG_OMS: return "OMS";
+    case CC_ALG_SCMS1: return "SCMS1";
+    case CC_ALG_SCMS2: return "SCMS2";
+    case CC_ALG_2DNMS: return "2DNMS";
+    default: return "?";
+  }
+}
+
+}  // namespace
+}  // namespace ccamd
+
+using namespace ccamd;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *cc_version(void) { return "channelcoding_amd 0.1 (gfx950, ABI 1)"; }
+
+const char *cc_status_string(int s) {
+  switch (s) {
+    case CC_OK: return "ok";
+    case CC_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case CC_ERR_UNSUPPORTED: return "not supported on the device path";
+    case CC_ERR_NO_DEVICE: return "no usable HIP device";
+    case CC_ERR_HIP: return "HIP runtime error";
+    case CC_ERR_OUT_OF_MEMORY: return "out of memory";
+    case CC_ERR_LENGTH: return "sequence has the wrong length";
+    case CC_ERR_NOT_IN_FIELD: return "value is not an element of the field";
+    default: return "unknown status";
+  }
+}
+
+const char *cc_last_error(void) { return g_last_error.c_str(); }
+
+void cc_desc_init(cc_desc *d) {
+  if (!d) return;
+  std::memset(d, 0, sizeof *d);
+  d->struct_size = sizeof *d;
+  d->family = CC_FAMILY_BCH;
+  d->mu = 1;
+  d->step = 1;
+  d->coding = CC_CODING_DIVISION;
+  d->algorithm = CC_ALG_PGZ;  // the reference's default Sigma, bch.h:17
+  d->iterations = 50;         // min_sum_tag<Iterations = 50>, soft_decision.h:20
+  d->alpha = 1.0;
+  d->beta = 0.0;
+  d->stop_rule = CC_STOP_PARITY;
+  d->device = -1;
+}
+
+int cc_code_create(const cc_desc *desc, cc_code **out) {
+  if (!desc || !out || desc->struct_size != sizeof(cc_desc)) return CC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!is_soft(desc->algorithm) && !is_hard(desc->algorithm)) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->family != CC_FAMILY_BCH && desc->family != CC_FAMILY_RS) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->stop_rule < CC_STOP_AS_SHIPPED || desc->stop_rule > CC_STOP_PARITY) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->coding != CC_CODING_DIVISION && desc->coding != CC_CODING_MULTIPLICATION) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->q < 2 || desc->q > 8) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->n != 0 && desc->n != (1u << desc->q) - 1) {
+    set_last_error("shortened codes (N != 2^q-1) are not supported");
+    return CC_ERR_UNSUPPORTED;
+  }
+  int dev = desc->device;
+  if (dev != CC_DEVICE_NONE) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      set_last_error("no HIP device: this library has no CPU fallback");
+      return CC_ERR_NO_DEVICE;
+    }
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return CC_ERR_NO_DEVICE;
+    if (dev < 0 || dev >= ndev) return CC_ERR_INVALID_ARGUMENT;
+  }
+
+  std::unique_ptr<cc_code> code(new (std::nothrow) cc_code());
+  if (!code) return CC_ERR_OUT_OF_MEMORY;
+  code->desc = *desc;
+  code->device = dev;
+  try {
+    code->field.reset(new Field(desc->q));
+    code->tab = build_code(*code->field, desc->family, desc->t, desc->mu, desc->step);
+  } catch (const std::invalid_argument &e) {
+    set_last_error(e.what());
+    return CC_ERR_INVALID_ARGUMENT;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return CC_ERR_INVALID_ARGUMENT;
+  }
+  code->soft = is_soft(desc->algorithm);
+  const CodeTables &t = code->tab;
+  {
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "(%u, %u, %u)-%s", t.n, t.l, t.dmin, alg_name(desc->algorithm));
+    code->name = buf;
+  }
+  if (code->soft && !t.binary_h) {
+    set_last_error("min-sum over a non-binary parity-check matrix (RS) is not supported");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (dev == CC_DEVICE_NONE) {
+    *out = code.release();
+    return CC_OK;
+  }
+  DeviceGuard guard(dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) code->num_cus = prop.multiProcessorCount;
+
+  if (code->soft) {
+    MinSumGeometry &g = code->geo;
+    if (t.n <= 16) {
+      g.W = 16;
+      g.C = 1;
+    } else if (t.n <= 32) {
+      g.W = 32;
+      g.C = 1;
+    } else if (t.n <= 64) {
+      g.W = 64;
+      g.C = 1;
+    } else if (t.n <= 128) {
+      g.W = 64;
+      g.C = 2;
+    } else {
+      g.W = 64;
+      g.C = 4;
+    }
+    g.frames_per_wave = 64 / g.W;
+    g.KW = static_cast<int>((t.k + 31) / 32);
+    std::vector<uint32_t> cm(static_cast<size_t>(g.KW) * g.C * 64, 0u);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int li = lane % g.W;
+      for (int c = 0; c < g.C; ++c) {
+        const unsigned j = static_cast<unsigned>(li + g.W * c);
+        if (j >= t.n) continue;
+        for (unsigned i = 0; i < t.k && i <= j; ++i)  // H[i][j] = row0[j - i], cyclic.h:346-359
+          if (t.row0[j - i]) cm[(static_cast<size_t>(i >> 5) * g.C + c) * 64 + lane] |= 1u << (i & 31);
+      }
+    }
+    CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
+    CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  AlgebraicTables &a = code->h_alg;
+  std::memset(&a, 0, sizeof a);
+  std::memcpy(a.exp, code->field->exp.data(), code->field->exp.size());
+  std::memcpy(a.log, code->field->log.data(), code->field->log.size());
+  std::memcpy(a.g, t.g.data(), t.g.size());
+  for (size_t i = 0; i < t.root_powers.size() && i < 64; ++i) a.roots_log[i] = static_cast<uint8_t>(t.root_powers[i]);
+  a.n = static_cast<int>(t.n);
+  a.k = static_cast<int>(t.k);
+  a.l = static_cast<int>(t.l);
+  a.t = static_cast<int>(t.t);
+  a.nroots = static_cast<int>(t.roots.size());
+  a.family = t.family;
+  a.q = static_cast<int>(t.q);
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_alg), sizeof a));
+  CC_HIP_TRY(hipMemcpy(code->d_alg, &a, sizeof a, hipMemcpyHostToDevice));
+
+  *out = code.release();
+  return CC_OK;
+}
+
+void cc_code_destroy(cc_code *code) {
+  if (!code) return;
+  if (code->device != CC_DEVICE_NONE) {
+    DeviceGuard guard(code->device);
+    if (code->d_colmask) (void)hipFree(code->d_colmask);
+    if (code->d_alg) (void)hipFree(code->d_alg);
+  }
+  delete code;
+}
+
+uint32_t cc_n(const cc_code *c) { return c ? c->tab.n : 0; }
+uint32_t cc_k(const cc_code *c) { return c ? c->tab.k : 0; }
+uint32_t cc_l(const cc_code *c) { return c ? c->tab.l : 0; }
+uint32_t cc_t(const cc_code *c) { return c ? c->tab.t : 0; }
+uint32_t cc_dmin(const cc_code *c) { return c ? c->tab.dmin : 0; }
+double cc_rate(const cc_code *c) { return c ? static_cast<double>(c->tab.l) / c->tab.n : 0.0; }
+
+int cc_to_string(const cc_code *c, char *out, size_t cap) {
+  if (!c || !out || cap == 0) return CC_ERR_INVALID_ARGUMENT;
+  std::snprintf(out, cap, "%s", c->name.c_str());
+  return CC_OK;
+}
+
+int cc_get_poly(const cc_code *c, int which, uint8_t *out, size_t cap) {
+  if (!c || !out) return -1;
+  const std::vector<uint8_t> *v = which == 0 ? &c->tab.g : which == 1 ? &c->tab.h : which == 2 ? &c->tab.roots : nullptr;
+  if (!v || v->size() > cap) return -1;
+  std::memcpy(out, v->data(), v->size());
+  return static_cast<int>(v->size());
+}
+
+int cc_get_H(const cc_code *c, uint8_t *H) {
+  if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
+  const unsigned n = c->tab.n;
+  for (unsigned i = 0; i < c->tab.k; ++i)
+    for (unsigned j = 0; j < n; ++j) H[i * n + j] = c->tab.row0[(j + n - i) % n];
+  return CC_OK;
+}
+
+double cc_sigma(const cc_code *c, double ebno_db) {
+  if (!c) return 0.0;
+  return 1.0 / std::sqrt(2.0 * cc_rate(c) * std::pow(10.0, ebno_db / 10.0));  // simulation.c++:83-85
+}
+
+/* ------------------------------ soft decode ------------------------------ */
+
+int cc_correct_soft_batch_dev(const cc_code *code, const float *d_llr, const uint16_t *d_erasures,
+                              const uint32_t *d_erasure_offsets, uint8_t *d_hard, float *d_L, uint16_t *d_iters,
+                              int32_t *d_status, size_t B, void *stream) {
+  if (!code || (B && (!d_llr || !d_hard))) return CC_ERR_INVALID_ARGUMENT;
+  if ((d_erasures == nullptr) != (d_erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  if (!code->soft) {
+    set_last_error("code was created with a hard-decision algorithm; use cc_correct_hard_f32_batch");
+    return CC_ERR_INVALID_ARGUMENT;
+  }
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  DeviceGuard guard(code->device);
+  return launch_minsum(code, d_llr, d_erasures, d_erasure_offsets, d_hard, d_L, d_iters, d_status, B,
+                       static_cast<hipStream_t>(stream));
+}
+
+int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t *erasures,
+                          const uint32_t *erasure_offsets, uint8_t *hard, float *L, uint16_t *iters, int32_t *status,
+                          size_t B) {
+  if (!code || (B && (!llr || !hard))) return CC_ERR_INVALID_ARGUMENT;
+  if ((erasures == nullptr) != (erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  if (B == 0) return CC_OK;
+  DeviceGuard guard(code->device);
+  const size_t n = code->tab.n;
+  DevBuf<float> d_llr, d_L;
+  DevBuf<uint8_t> d_hard;
+  DevBuf<uint16_t> d_iters, d_er;
+  DevBuf<uint32_t> d_off;
+  DevBuf<int32_t> d_status;
+  CC_HIP_TRY(d_llr.alloc(B * n));
+  CC_HIP_TRY(d_hard.alloc(B * n));
+  CC_HIP_TRY(d_iters.alloc(B));
+  CC_HIP_TRY(d_status.alloc(B));
+  if (L) CC_HIP_TRY(d_L.alloc(B * n));
+  CC_HIP_TRY(hipMemcpy(d_llr.p, llr, B * n * sizeof(float), hipMemcpyHostToDevice));
+  if (erasures) {
+    const size_t ne = erasure_offsets[B];
+    for (size_t e = 0; e < ne; ++e)
+      if (erasures[e] >= n) return CC_ERR_INVALID_ARGUMENT;  // copy.at(erasure) would throw, cyclic.h:261
+    CC_HIP_TRY(d_er.alloc(ne + 1));
+    CC_HIP_TRY(d_off.alloc(B + 1));
+    if (ne) CC_HIP_TRY(hipMemcpy(d_er.p, erasures, ne * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CC_HIP_TRY(hipMemcpy(d_off.p, erasure_offsets, (B + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  int rc = cc_correct_soft_batch_dev(code, d_llr.p, d_er.p, d_off.p, d_hard.p, d_L.p, d_iters.p, d_status.p, B, nullptr);
+  if (rc != CC_OK) return rc;
+  CC_HIP_TRY(hipDeviceSynchronize());
+  CC_HIP_TRY(hipMemcpy(hard, d_hard.p, B * n, hipMemcpyDeviceToHost));
+  if (L) CC_HIP_TRY(hipMemcpy(L, d_L.p, B * n * sizeof(float), hipMemcpyDeviceToHost));
+  if (iters) CC_HIP_TRY(hipMemcpy(iters, d_iters.p, B * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (status) CC_HIP_TRY(hipMemcpy(status, d_status.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
+                   uint32_t *threads_per_workgroup, uint32_t *lds_bytes) {
+  if (!code) return CC_ERR_INVALID_ARGUMENT;
+  std::string nm = "algebraic";
+  uint32_t f = 0, t = 0, l = 0;
+  if (code->soft) minsum_kernel_info(code, nm, f, t, l);
+  if (name && cap) std::snprintf(name, cap, "%s", nm.c_str());
+  if (frames_per_workgroup) *frames_per_workgroup = f;
+  if (threads_per_workgroup) *threads_per_workgroup = t;
+  if (lds_bytes) *lds_bytes = l;
+  return CC_OK;
+}
+
+/* ---- entry points whose kernels land in the next milestones: present in the
+ *      ABI, fail loudly (never a CPU fallback) until then ---- */
+static int not_yet(const char *what) {
+  set_last_error(std::string(what) + ": device kernel not built into this library version");
+  return CC_ERR_UNSUPPORTED;
+}
+
+int cc_encode_batch(const cc_code *, const uint8_t *, uint8_t *, size_t) { return not_yet("cc_encode_batch"); }
+int cc_encode_batch_dev(const cc_code *, const uint8_t *, uint8_t *, size_t, void *) {
+  return not_yet("cc_encode_batch_dev");
+}
+int cc_correct_hard_batch(const cc_code *, const uint8_t *, const uint16_t *, const uint32_t *, uint8_t *, int32_t *,
+                          int32_t *, size_t) {
+  return not_yet("cc_correct_hard_batch");
+}
+int cc_correct_hard_batch_dev(const cc_code *, const uint8_t *, const uint16_t *, const uint32_t *, uint8_t *,
+                              int32_t *, int32_t *, size_t, void *) {
+  return not_yet("cc_correct_hard_batch_dev");
+}
+int cc_correct_hard_f32_batch(const cc_code *, const float *, uint8_t *, int32_t *, int32_t *, size_t) {
+  return not_yet("cc_correct_hard_f32_batch");
+}
+int cc_correct_hard_f32_batch_dev(const cc_code *, const float *, uint8_t *, int32_t *, int32_t *, size_t, void *) {
+  return not_yet("cc_correct_hard_f32_batch_dev");
+}
+int cc_extract_batch(const cc_code *, const uint8_t *, uint8_t *, size_t) { return not_yet("cc_extract_batch"); }
+int cc_extract_batch_dev(const cc_code *, const uint8_t *, uint8_t *, size_t, void *) {
+  return not_yet("cc_extract_batch_dev");
+}
+int cc_mc_run_dev(const cc_code *, double, uint64_t, uint64_t, size_t, int, uint64_t *, void *) {
+  return not_yet("cc_mc_run_dev");
+}
+int cc_awgn_llr_dev(const cc_code *, double, uint64_t, uint64_t, size_t, int, float *, uint8_t *, void *) {
+  return not_yet("cc_awgn_llr_dev");
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

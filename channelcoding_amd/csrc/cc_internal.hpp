@@ -1,0 +1,78 @@
+// cc_internal.hpp -- shared between the C-ABI translation unit and the kernel
+// launchers.  Not installed; the public contract is include/channelcoding_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+
+#include "../../include/channelcoding_amd.h"
+#include "galois.hpp"
+
+namespace ccamd {
+
+// Geometry of the min-sum kernels: a frame occupies W consecutive lanes of a
+// wave64 (W = 16 / 32 / 64), lane `li` of the group owns the columns
+// j = li + W*c, c < C.  Parity-check row i touches column j iff row0[j - i] != 0
+// (H is banded Toeplitz: cyclic.h:346-359), so connectivity is a per-lane bit
+// mask over rows: colmask[(w*C + c)*64 + lane] bit (i & 31), w = i >> 5.
+struct MinSumGeometry {
+  int W = 64, C = 4, frames_per_wave = 1, KW = 1;
+};
+
+struct MinSumParams {
+  int n, K, KW;
+  int variant;      // cc_algorithm
+  int stop_rule;    // cc_stop_rule
+  unsigned iterations;
+  float alpha_f;    // NMS / 2D-NMS horizontal factor (soft_decision.h:211-213: const R& alpha)
+  float beta_f;     // 2D-NMS vertical factor        (soft_decision.h:215-218: const R& beta)
+  double beta_d;    // OMS offset, evaluated in double (soft_decision.h:245-251)
+  const uint32_t *colmask;  // device
+};
+
+// device-resident tables of one code for the algebraic chain and the encoder
+struct AlgebraicTables {
+  uint8_t exp[512];
+  uint8_t log[512];
+  uint8_t g[256];
+  uint8_t roots_log[64];
+  int n, k, l, t, nroots, family, q;
+};
+
+}  // namespace ccamd
+
+struct cc_code {
+  cc_desc desc;
+  int device = 0;
+  std::unique_ptr<ccamd::Field> field;
+  ccamd::CodeTables tab;
+  bool soft = false;
+  ccamd::MinSumGeometry geo;
+  uint32_t *d_colmask = nullptr;
+  ccamd::AlgebraicTables *d_alg = nullptr;
+  ccamd::AlgebraicTables h_alg;
+  uint32_t *d_zero_offsets = nullptr;  // scratch: unused
+  int num_cus = 256;
+  std::string name;
+};
+
+namespace ccamd {
+
+void set_last_error(const std::string &s);
+int hip_fail(hipError_t e, const char *what);
+
+#define CC_HIP_TRY(expr)                                   \
+  do {                                                     \
+    hipError_t _e = (expr);                                \
+    if (_e != hipSuccess) return ccamd::hip_fail(_e, #expr); \
+  } while (0)
+
+// minsum.hip
+int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er, const uint32_t *d_er_off,
+                  uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream);
+int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
+                       uint32_t &lds);
+
+}  // namespace ccamd

@@ -1,0 +1,154 @@
+"""GPU parity tests of the min-sum path, called through the C ABI
+(cc_correct_soft_batch / _dev) and checked against (a) the committed golden
+vectors produced by the real reference and (b) the plain-C oracle on fresh
+seeded inputs.  Bar: hard decisions, iteration index and failure flag
+bit-exact; L within 1e-5 (north_star) -- asserted bit-exact as well.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+from checkers import BCH, O0, O1, O2, REF_CODES, REF_VARIANTS, Oracle, awgn_llr
+
+import channelcoding_amd as cc
+from channelcoding_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+TAG = {
+    0: lambda it, a, b: cc.min_sum_tag(it),
+    1: lambda it, a, b: cc.normalized_min_sum_tag(it, a),
+    2: lambda it, a, b: cc.offset_min_sum_tag(it, b),
+    3: lambda it, a, b: cc.self_correcting_1_min_sum_tag(it),
+    4: lambda it, a, b: cc.self_correcting_2_min_sum_tag(it),
+    5: lambda it, a, b: _d2(it, a, b),
+}
+
+
+def _d2(it, a, b):
+    t = cc.normalized_2d_min_sum_tag(it)
+    t.alpha, t.beta = a, b  # the tag's ::alpha / ::beta constants as the reference computes them
+    return t
+
+
+def make_code(cid, ov, alpha, beta, iters, stop):
+    fam, q, t = REF_CODES[cid]
+    assert fam == BCH
+    return cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta), stop_rule=stop)
+
+
+def check(res, b, L, it, st, tag=""):
+    assert np.array_equal(res["status"] != 0, st != 0), tag
+    assert np.array_equal(res["out"], b), tag  # also on failed frames: last iteration's hard decision
+    assert np.array_equal(res["iters"], it), tag
+    if "L" in res:
+        assert np.allclose(res["L"], L, rtol=0, atol=1e-5), tag
+        assert np.array_equal(res["L"], L), tag
+
+
+@pytest.mark.parametrize("cid", G.SOFT_CIDS)
+def test_minsum_golden(cid):
+    """HIP path vs the real reference's outputs (tests/golden, all variants x O0/O1/O2)."""
+    d = G.load("minsum", cid)
+    y, iters = d["y"], int(d["iterations"])
+    o = Oracle(*REF_CODES[cid])
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in G.minsum_cases(cid):
+        code = make_code(cid, ov, alpha, beta, iters, rule)
+        res = code.correct_batch(y, want_L=True)
+        ok = gst == 0
+        assert np.array_equal(res["status"] != 0, gst != 0), (v, rule)
+        assert np.array_equal(res["out"][ok], gb[ok]), (v, rule)
+        assert np.array_equal(res["iters"][ok], git[ok]), (v, rule)
+        assert np.allclose(res["L"][ok], gL[ok], rtol=0, atol=1e-5), (v, rule)
+        # frames on which the reference throws carry no reference output: compare those with the oracle
+        ob, oL, oit, ost = o.minsum(ov, iters, y, alpha, beta, rule, fast=True)
+        check(res, ob, oL, oit, ost, (v, rule))
+
+
+@pytest.mark.parametrize("cid,iters,frames", [(0, 10, 301), (1, 10, 130), (4, 50, 203), (12, 20, 97), (5, 10, 257),
+                                              (13, 10, 66), (11, 20, 65), (6, 20, 48)])
+def test_minsum_vs_oracle_seeded(cid, iters, frames):
+    """Fresh seeded inputs (all-zero and random codewords, three noise levels), ragged batch sizes."""
+    o = Oracle(*REF_CODES[cid])
+    rng = np.random.default_rng(4000 + cid)
+    cw = o.encode(rng.integers(0, 2, (frames, o.l)).astype(np.uint8))
+    cw[: frames // 3] = 0
+    ebno = rng.choice([1.0, 4.0, 7.0], frames)
+    y = np.concatenate([awgn_llr(rng, cw[f:f + 1], o.l / o.n, ebno[f]) for f in range(frames)])
+    for v in sorted(REF_VARIANTS):
+        ov, alpha, beta = REF_VARIANTS[v]
+        for rule in (O0, O1, O2):
+            if cid == 6 and (v, rule) not in ((0, O2), (0, O1), (1, O2), (2, O2), (3, O2), (4, O2), (6, O2), (0, O0)):
+                continue  # keep the n=255 oracle time bounded
+            code = make_code(cid, ov, alpha, beta, iters, rule)
+            res = code.correct_batch(y, want_L=True)
+            check(res, *o.minsum(ov, iters, y, alpha, beta, rule, fast=True), tag=(cid, v, rule))
+
+
+def test_minsum_edge_cases():
+    o = Oracle(BCH, 6, 3)
+    code = cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(10))
+    # empty batch
+    res = code.correct_batch(np.zeros((0, 63), np.float32))
+    assert res["out"].shape == (0, 63)
+    # single frame; exact zeros, ties, +-0.0, huge and denormal values
+    y = np.ones((5, 63), np.float32)
+    y[1, :] = 0.0
+    y[2, ::2] = -0.0
+    y[3, :8] = [1e30, -1e30, 1e-40, -1e-40, 0.5, 0.5, -0.5, 0.25]
+    y[4, :] = np.float32(-1.0)  # all-ones word is a codeword of BCH(63,45)? decided by the oracle
+    for rule in (O0, O1, O2):
+        for ov, tag in ((0, cc.min_sum_tag(10)), (3, cc.self_correcting_1_min_sum_tag(10)),
+                        (4, cc.self_correcting_2_min_sum_tag(10)), (2, cc.offset_min_sum_tag(10, (1, 100)))):
+            c = cc.primitive_bch(6, cc.errors(3), tag, stop_rule=rule)
+            res = c.correct_batch(y, want_L=True)
+            check(res, *o.minsum(ov, 10, y, 1.0, 0.01 if ov == 2 else 0.0, rule, fast=True), tag=(ov, rule))
+    # wrong length -> the reference's runtime_error (cyclic.h:213-218)
+    with pytest.raises(cc.CcError) as e:
+        code.correct_batch(np.zeros((2, 62), np.float32))
+    assert e.value.status == capi.ERR_LENGTH
+    # single-frame API raises decoding_failure like the reference
+    bad = awgn_llr(np.random.default_rng(1), np.zeros((1, 63), np.uint8), 45 / 63, -3.0)[0]
+    st = o.minsum(0, 10, bad, stop=O2, fast=True)[3][0]
+    if st != 0:
+        with pytest.raises(cc.decoding_failure):
+            code.correct(bad)
+    good = np.ones(63, np.float32)
+    assert not code.correct(good).any()
+
+
+def test_minsum_erasures():
+    """cyclic.h:259-262: erasures zero the LLR before decoding (per-frame CSR lists)."""
+    o = Oracle(BCH, 6, 3)
+    rng = np.random.default_rng(5)
+    B = 70
+    y = awgn_llr(rng, np.zeros((B, 63), np.uint8), 45 / 63, 5.0)
+    per = [sorted(rng.choice(63, int(rng.integers(0, 5)), replace=False).tolist()) for _ in range(B)]
+    code = cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(10))
+    res = code.correct_batch(y, erasures=per, want_L=True)
+    for f in range(B):
+        ob, oL, oit, ost = o.minsum(0, 10, y[f], stop=O2, erasures=per[f])
+        assert res["status"][f] == ost[0] and np.array_equal(res["out"][f], ob[0]) and res["iters"][f] == oit[0]
+        assert np.array_equal(res["L"][f], oL[0])
+
+
+def test_minsum_device_pointers():
+    """The _dev entry point on torch CUDA tensors (plumbing: data_ptr + current stream)."""
+    import torch
+    o = Oracle(BCH, 8, 3)
+    rng = np.random.default_rng(6)
+    B = 1000
+    y = awgn_llr(rng, np.zeros((B, 255), np.uint8), 231 / 255, 5.0)
+    code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20))
+    ty = torch.from_numpy(y).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        res = code.correct_batch(ty, want_L=True)
+    s.synchronize()
+    host = code.correct_batch(y, want_L=True)
+    for key in ("out", "status", "iters", "L"):
+        assert np.array_equal(res[key].cpu().numpy().astype(host[key].dtype), host[key]), key
+    sub = slice(0, 64)
+    ob, oL, oit, ost = o.minsum(0, 20, y[sub], stop=O2, fast=True)
+    assert np.array_equal(host["out"][sub], ob) and np.array_equal(host["L"][sub], oL)
+    assert np.array_equal(host["iters"][sub], oit) and np.array_equal(host["status"][sub], ost)

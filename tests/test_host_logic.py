@@ -1,0 +1,98 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the
+header declares, builds the same code constants as the reference (golden
+constants.json), and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from checkers import REF_CODES
+
+import channelcoding_amd as cc
+from channelcoding_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "channelcoding_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cc_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(capi.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert syms == capi.exported_symbols()  # the ctypes table binds exactly the header
+    assert b"gfx950" in capi.lib().cc_version()
+
+
+def _host_code(family, q, t, alg=capi.ALG_BM, **kw):
+    cls = cc.primitive_bch if family == 0 else cc.rs
+    tag = {capi.ALG_PGZ: cc.peterson_gorenstein_zierler_tag, capi.ALG_BM: cc.berlekamp_massey_tag,
+           capi.ALG_EUKLID: cc.euklid_tag}[alg]
+    return cls(q, cc.errors(t), tag(), device=capi.DEVICE_NONE, **kw)
+
+
+def test_code_constants_match_reference():
+    for cid, c in G.constants().items():
+        fam, q, t = REF_CODES[cid]
+        for alg, name in ((capi.ALG_PGZ, "PGZ"), (capi.ALG_BM, "BM"), (capi.ALG_EUKLID, "EUKLID")):
+            code = _host_code(fam, q, t, alg)
+            assert code.to_string() == c["to_string"][name]
+        assert (code.n, code.k, code.l, code.t, code.dmin) == (c["n"], c["k"], c["l"], c["t"], c["dmin"])
+        assert abs(code.rate - c["rate"]) < 1e-15
+        assert list(code.g) == c["g"] and list(code.h) == c["h"] and list(code.roots) == c["roots"]
+        H = code.H()
+        assert [j for j in range(code.n) if H[0, j]] == c["row0_support"]
+        for i in range(1, code.k):
+            assert np.array_equal(H[i, i:], H[0, : code.n - i]) and not H[i, :i].any()
+
+
+def test_capability_and_tags():
+    assert cc.dmin(7).t == 3 and cc.dmin(6).t == 2 and cc.errors(2).t == 2  # codes.h:19-26
+    d2 = cc.normalized_2d_min_sum_tag(10)
+    assert (d2.alpha, d2.beta) == (1.0, 1.0)  # Q11: defaults collapse to plain MS
+    d2 = cc.normalized_2d_min_sum_tag(10, (3, 4), (9, 10))
+    assert (d2.alpha, d2.beta) == (0.75, 2.25)
+    assert cc.normalized_min_sum_tag(10, (8, 10)).alpha == 0.8
+    assert cc.offset_min_sum_tag(10, (1, 100)).beta == 0.01
+    soft = cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(10), device=capi.DEVICE_NONE)
+    assert soft.to_string() == "(63, 45, 7)-MS"
+    assert cc.primitive_bch(5, cc.dmin(7), cc.self_correcting_2_min_sum_tag(), device=capi.DEVICE_NONE).to_string() \
+        == "(31, 16, 7)-SCMS2"
+
+
+def test_invalid_descriptors():
+    with pytest.raises(cc.CcError):
+        cc.primitive_bch(9, cc.errors(2), device=capi.DEVICE_NONE)  # q > 8: no default modular polynomial
+    with pytest.raises(cc.CcError):
+        cc.primitive_bch(4, cc.errors(8), device=capi.DEVICE_NONE)
+    with pytest.raises(cc.CcError) as e:
+        cc.rs(4, cc.errors(3), cc.min_sum_tag(10), device=capi.DEVICE_NONE)  # non-binary H
+    assert e.value.status == capi.ERR_UNSUPPORTED
+
+
+def test_no_cpu_fallback():
+    """Without a device every compute entry point fails loudly."""
+    code = cc.primitive_bch(4, cc.errors(2), cc.min_sum_tag(10), device=capi.DEVICE_NONE)
+    y = np.ones((2, 15), np.float32)
+    with pytest.raises(cc.CcError) as e:
+        code.correct_batch(y)
+    assert e.value.status == capi.ERR_NO_DEVICE
+    hard = cc.primitive_bch(4, cc.errors(2), cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE)
+    for fn, arg in ((hard.correct_batch, np.zeros((1, 15), np.uint8)), (hard.encode_batch, np.zeros((1, 7), np.uint8))):
+        with pytest.raises(cc.CcError) as e:
+            fn(arg)
+        assert e.value.status in (capi.ERR_NO_DEVICE, capi.ERR_UNSUPPORTED)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(cc.CcError) as e:
+            cc.primitive_bch(4, cc.errors(2))  # default device: needs a GPU
+        assert e.value.status == capi.ERR_NO_DEVICE
