@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: BCH(255,231,t=3) min-sum decode, batch 2^20 frames per GPU.
+
+One "step" = one pass of the hot path (cc_correct_soft_batch_dev: LLR frames resident in HBM ->
+hard decisions + iteration index + status) over one batch.  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--ebno 4.0] [--batch-log2 20]
+  (N > 1: launched by torch.distributed.run, one rank per GPU; frames are independent, so ranks
+   shard the batch with no data-path collective -> weak scaling; timing = max over ranks.)
+
+roofline.achieved = algorithmic HBM bytes per launch (4n LLR bytes in + n hard bytes out + 6 B
+iters/status per frame) / average kernel duration measured with HIP events on the
+launch stream.  cpu_baseline = the real reference (oracle/_ref, built from /root/reference in the
+dev container) or, if that prebuilt library is absent, the plain-C oracle, timed on a bounded sample
+of the same frames on one host core.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 measured attainable
+
+
+def cpu_baseline(y_sample, iterations, budget_s=20.0):
+    """Reference CPU path on this box's host cores (1 thread: the reference decodes frames sequentially,
+    src/simulation/simulation.c++:124-136).  Same frames as the GPU workload, stop rule O2."""
+    from checkers import BCH, O2, Oracle, RefLib
+    n = y_sample.shape[1]
+    if RefLib.available():
+        ref = RefLib.get(1)
+        # calibrate on a few frames, then size the sample to the budget
+        t0 = time.perf_counter()
+        ref.minsum(6, 0, iterations, 1, y_sample[:8])
+        per = max((time.perf_counter() - t0) / 8, 1e-4)
+        m = int(max(16, min(len(y_sample), budget_s / per)))
+        ref.minsum(6, 0, iterations, 1, y_sample[:m])
+        sec = ref.last_seconds
+        kind, what = "reference", "oracle/_ref/libccref_o1.so: min_sum<float, ef_element<2,1>>(H(), y, min_sum_tag<%d>), H rebuilt per frame" % iterations
+    else:
+        o = Oracle(BCH, 8, 3)
+        m = min(len(y_sample), 2000)
+        t0 = time.perf_counter()
+        o.minsum(0, iterations, y_sample[:m], stop=O2, fast=True)
+        sec = time.perf_counter() - t0
+        kind, what = "port", "oracle/cc_oracle.c orc_minsum_fast (O(w) restatement)"
+    return dict(value=m / sec, unit="frames/s", cores=1, kind=kind,
+                sample="%d of the benchmark's frames, %.1f s, %s" % (m, sec, what), host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ebno", type=float, default=4.0)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--stop-rule", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import channelcoding_amd as cc
+    from channelcoding_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+
+    dev = torch.device("cuda", local_rank)
+    B = 1 << args.batch_log2
+    code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(args.iterations), stop_rule=args.stop_rule)
+    n = code.n
+    sigma = code.sigma(args.ebno)
+
+    # synthetic input: all-zero codeword (as the reference's awgn_simulation, simulation.c++:113-125),
+    # y = 1 + sigma*N(0,1) in f32; each rank owns a different shard of the global frame sequence.
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    y = torch.empty((B, n), dtype=torch.float32, device=dev)
+    y.normal_(mean=1.0, std=float(sigma), generator=gen)
+    hard = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    iters = torch.empty(B, dtype=torch.int16, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    lib = capi.lib()
+    stream = torch.cuda.current_stream(dev)
+    sh = C.c_void_p(stream.cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def step():
+        rc = lib.cc_correct_soft_batch_dev(code._h, vp(y), None, None, vp(hard), None, vp(iters), vp(status), B, sh)
+        if rc != 0:
+            raise cc.CcError(rc, "cc_correct_soft_batch_dev")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    it_host = iters.to(torch.int32)
+    conv = int((status == 0).sum().item())
+    iters_run = torch.where(status == 0, it_host + 1, it_host)  # iterations actually executed
+    mean_iters = float(iters_run.float().mean().item())
+
+    if rank == 0:
+        frames_per_s = world * B * args.steps / elapsed
+        bytes_per_frame = 5 * n + 6
+        achieved = bytes_per_frame * B / (kernel_ms * 1e-3) / 1e9
+        name = C.create_string_buffer(128)
+        fpw, thr, ldsb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.cc_kernel_info(code._h, name, 128, C.byref(fpw), C.byref(thr), C.byref(ldsb))
+        out = {
+            "metric": "decoded frames/sec (coded bits/sec = value x 255), BCH(255,231) min-sum, batch=2^%d" % args.batch_log2,
+            "value": frames_per_s,
+            "unit": "frames/s",
+            "coded_bits_per_sec": frames_per_s * n,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BCH(255,231,t=3) min-sum MS<%d>, stop rule O%d, all-zero codeword + AWGN Eb/N0=%.1f dB "
+                            "(sigma=%.6f), batch=2^%d frames per GPU, LLR f32 resident in HBM -> hard bytes + iters + status"
+                            % (args.iterations, args.stop_rule, args.ebno, sigma, args.batch_log2),
+                "frames_per_gpu": B, "n": n, "iterations_max": args.iterations,
+                "mean_iterations_run": mean_iters, "converged_fraction": conv / B,
+                "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": name.value.decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bytes_per_frame,
+                "note": "path is VALU-issue bound, not HBM bound (SURVEY F4): %.1f min-sum iterations per frame on average"
+                        % mean_iters,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(y[:4096].cpu().numpy(), args.iterations)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,13 @@ def lib():
             raise ImportError(
                 "channelcoding_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C channelcoding_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # torch wheels bundle their own libamdhip64.so; two HIP runtimes cannot share one process
+        # ("No HIP GPUs are available" for whichever initialises second).  Loading torch first makes our
+        # library bind to the runtime torch already mapped, so both see the same devices and streams.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
