@@ -5,6 +5,7 @@
 // CPU decode path in this library.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -144,6 +145,10 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
     return CC_ERR_INVALID_ARGUMENT;
   }
   code->soft = is_soft(desc->algorithm);
+  {
+    const char *fg = std::getenv("CC_AMD_FORCE_GENERIC");
+    code->force_generic = fg && fg[0] == '1';
+  }
   const CodeTables &t = code->tab;
   {
     char buf[96];
@@ -194,6 +199,17 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
     }
     CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
     CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (g.W == 64) {
+      std::vector<uint64_t> em(static_cast<size_t>(t.k) * g.C, 0ull);
+      for (unsigned i = 0; i < t.k; ++i)
+        for (int c = 0; c < g.C; ++c)
+          for (unsigned lane = 0; lane < 64; ++lane) {
+            const unsigned j = lane + 64u * static_cast<unsigned>(c);
+            if (j < t.n && i <= j && t.row0[j - i]) em[i * g.C + c] |= 1ull << lane;
+          }
+      CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_emask), em.size() * sizeof(uint64_t)));
+      CC_HIP_TRY(hipMemcpy(code->d_emask, em.data(), em.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
   }
   AlgebraicTables &a = code->h_alg;
   std::memset(&a, 0, sizeof a);
@@ -220,6 +236,7 @@ void cc_code_destroy(cc_code *code) {
   if (code->device != CC_DEVICE_NONE) {
     DeviceGuard guard(code->device);
     if (code->d_colmask) (void)hipFree(code->d_colmask);
+    if (code->d_emask) (void)hipFree(code->d_emask);
     if (code->d_alg) (void)hipFree(code->d_alg);
   }
   delete code;

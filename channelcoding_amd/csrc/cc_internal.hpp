@@ -51,10 +51,12 @@ struct cc_code {
   bool soft = false;
   ccamd::MinSumGeometry geo;
   uint32_t *d_colmask = nullptr;
+  uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
   ccamd::AlgebraicTables *d_alg = nullptr;
   ccamd::AlgebraicTables h_alg;
   uint32_t *d_zero_offsets = nullptr;  // scratch: unused
   int num_cus = 256;
+  bool force_generic = false;  // CC_AMD_FORCE_GENERIC=1: A/B the generic kernel against the fast one
   std::string name;
 };
 
@@ -72,6 +74,12 @@ int hip_fail(hipError_t e, const char *what);
 // minsum.hip
 int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er, const uint32_t *d_er_off,
                   uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream);
+// minsum_reg.hip
+bool minsum_reg_supported(const cc_code *code);
+const char *minsum_reg_name(const cc_code *code);
+int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
+                      const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
+                      size_t B, hipStream_t stream);
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds);
 

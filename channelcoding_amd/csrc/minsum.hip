@@ -257,6 +257,13 @@ size_t generic_lds_bytes(const cc_code *code) {
 
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds) {
+  if (minsum_reg_supported(code)) {
+    name = minsum_reg_name(code);
+    frames_per_wg = 4;
+    threads = 256;
+    lds = 0;
+    return CC_OK;
+  }
   name = "minsum_generic_kernel<C=" + std::to_string(code->geo.C) + ",W=" + std::to_string(code->geo.W) + ">";
   frames_per_wg = static_cast<uint32_t>(code->geo.frames_per_wave);
   threads = 64;
@@ -278,6 +285,9 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   p.beta_f = static_cast<float>(code->desc.beta);
   p.beta_d = code->desc.beta;
   p.colmask = code->d_colmask;
+
+  if (minsum_reg_supported(code) && !code->force_generic)
+    return launch_minsum_reg(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 
   const size_t lds = generic_lds_bytes(code);
   if (lds > 160 * 1024) {
