@@ -1,0 +1,271 @@
+// algebraic.hip -- hard-decision decoding chain over GF(2^q), one codeword per
+// wavefront, GF log/antilog tables staged in LDS.
+//
+// Replaces, per frame: cyclic::correct_(hard_decision_tag) src/codes/cyclic.h:207-252
+//   syndromes        calculate_syndromes cyclic.h:53-63 (Horner, polynomial.h:273-284)
+//   error locator    Berlekamp-Massey with erasure pre-load, hard_decision.h:116-155
+//   root search      cyclic::zeroes cyclic.h:126-150 (brute force over the field, polynomial.h:16-28)
+//   error values     primitive_bch::error_values bch.h:80-83 (all ones) /
+//                    rs::error_values rs.h:41-78 (the reference solves the v x v system by Gauss
+//                    elimination; here Forney's formula, which yields the same unique solution)
+//   apply + re-check cyclic.h:237-248
+//
+// Equivalences used (all exact field arithmetic, so results are identical, not approximate):
+//   * S_j = sum_p b_p alpha^(r_j p) instead of Horner;
+//   * the reference returns lambda reversed, whose roots are the locators X = alpha^pos;
+//     X is a root of reverse(lambda) iff lambda(X^-1) = 0, so lambda is evaluated at alpha^(-p);
+//   * the re-check "syndromes of the corrected word are all zero" is evaluated as
+//     "syndromes of the error pattern equal the received syndromes" (linearity);
+//   * the reference's BM reads lambda out of bounds when deg(lambda) < l; lanes
+//     beyond the degree hold zero here, which is the textbook algorithm.
+//   * PGZ and Euklid tags decode to the same word as BM whenever at most t errors (+ erasures
+//     within capability) occurred; they are run as "BM + degree bound" (bounded-distance
+//     decoding), see DESIGN.md for the reference defects this sidesteps (Q9).
+//
+// Lane roles: in the syndrome / root-search / verify phases lane l owns the positions
+// p = l + 64c (c < 4); in the Berlekamp-Massey phase lane j owns coefficient j of lambda and b.
+#include "cc_internal.hpp"
+#include "wave_ops.hpp"
+
+namespace ccamd {
+namespace {
+
+struct WaveScratch {
+  uint8_t S[64];    // syndromes
+  uint8_t lam[72];  // lambda coefficients
+  uint8_t om[72];   // omega coefficients
+};
+
+__device__ __forceinline__ uint32_t bcast63(uint32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+// lane j <- lane j-1, lane 0 <- 0   (multiplication of a polynomial by x)
+__device__ __forceinline__ uint32_t shift_up(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+
+template <bool FLOAT_IN>
+__global__ void __launch_bounds__(256)
+algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__restrict__ in_raw,
+                 const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off, uint8_t *__restrict__ out,
+                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
+  __shared__ uint8_t ex[512];
+  __shared__ uint8_t lg[256];
+  __shared__ WaveScratch scratch[4];
+  for (int i = threadIdx.x; i < 512; i += 256) ex[i] = T->exp[i];
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  WaveScratch &W = scratch[wid];
+  const int n = T->n, nroots = T->nroots, nn = n;  // full-length codes: n = 2^q - 1
+  const int t2 = nroots;
+  const bool is_rs = T->family == CC_FAMILY_RS;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+
+  auto gmul = [&](uint32_t a, uint32_t b) -> uint32_t { return (a && b) ? ex[lg[a] + lg[b]] : 0u; };
+  // a * alpha^e, 0 <= e < nn
+  auto gmul_pow = [&](uint32_t a, uint32_t e) -> uint32_t { return a ? ex[lg[a] + e] : 0u; };
+
+  // per-lane exponent bookkeeping: e0[c] = r_0 * p mod nn, d[c] = step * p mod nn (roots are alpha^(r_0 + j*step))
+  const int r0 = T->roots_log[0];
+  const int step = nroots > 1 ? (T->roots_log[1] + nn - r0) % nn : 0;
+  uint32_t e0[4], dstep[4], xinv[4];
+  bool valid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int p = lane + 64 * c;
+    valid[c] = p < n;
+    e0[c] = static_cast<uint32_t>((r0 * p) % nn);
+    dstep[c] = static_cast<uint32_t>((step * p) % nn);
+    xinv[c] = static_cast<uint32_t>((nn - (p % nn)) % nn);  // log of X^-1 for X = alpha^p
+  }
+
+  for (unsigned long long frame = wave; frame < B; frame += nwaves) {
+    // ---- load (hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52) ----
+    uint32_t sym[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int p = lane + 64 * c;
+      if (FLOAT_IN)
+        sym[c] = valid[c] ? (static_cast<const float *>(in_raw)[frame * n + p] < 0.0f ? 1u : 0u) : 0u;
+      else
+        sym[c] = valid[c] ? (static_cast<const uint8_t *>(in_raw)[frame * n + p] & static_cast<uint32_t>(n)) : 0u;
+    }
+    uint32_t nerase = 0, ebase = 0;
+    if (er_off != nullptr) {
+      ebase = er_off[frame];
+      nerase = er_off[frame + 1] - ebase;
+    }
+
+    // ---- syndromes, four per DPP reduction ----
+    uint32_t lsym[4], ecur[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lsym[c] = lg[sym[c]];
+      ecur[c] = e0[c];
+    }
+    uint32_t any_syndrome = 0;
+    for (int j0 = 0; j0 < t2; j0 += 4) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        uint32_t term = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          term ^= sym[c] ? ex[lsym[c] + ecur[c]] : 0u;
+          ecur[c] += dstep[c];
+          ecur[c] = ecur[c] >= static_cast<uint32_t>(nn) ? ecur[c] - nn : ecur[c];
+        }
+        packed |= (j0 + jj < t2 ? term : 0u) << (8 * jj);
+      }
+      packed = bcast63(wave_xor(packed));
+      any_syndrome |= packed;
+      if (lane < 4 && j0 + lane < t2) W.S[j0 + lane] = static_cast<uint8_t>(packed >> (8 * lane));
+    }
+
+    int status = CC_FRAME_OK;
+    int nerr = 0;
+    uint32_t corr[4] = {0, 0, 0, 0};
+    if (any_syndrome != 0) {  // wave-uniform
+      // ---- Berlekamp-Massey, hard_decision.h:116-155 (lane j <-> coefficient j) ----
+      uint32_t lam = (lane == 0) ? 1u : 0u;
+      for (uint32_t e = 0; e < nerase; ++e) {  // lambda *= (1 + alpha^erasure x), :128-131
+        const uint32_t X = ex[er[ebase + e] % nn];
+        lam ^= gmul(X, shift_up(lam));
+      }
+      uint32_t bpoly = lam;
+      int l = static_cast<int>(nerase);
+      const int rho = static_cast<int>(nerase);
+      for (int i = rho; i < t2; ++i) {
+        bpoly = shift_up(bpoly);  // b = b * x
+        const bool in_sum = lane >= 1 && lane <= l && lane <= i;
+        const uint32_t sij = in_sum ? W.S[i - lane] : 0u;
+        const uint32_t delta = (bcast63(wave_xor(gmul(lam, sij))) ^ W.S[i]) & 0xFFu;
+        if (delta != 0) {  // wave-uniform
+          const uint32_t tnew = lam ^ gmul(delta, bpoly);
+          if (2 * l <= i + rho) {
+            bpoly = lam ? ex[lg[lam] + nn - lg[delta]] : 0u;  // lambda * delta^-1
+            l = i + rho - l + 1;
+          }
+          lam = tnew;
+        }
+      }
+      const unsigned long long nz = __ballot(lam != 0);
+      const int deg = 63 - __builtin_clzll(nz | 1ull);
+      W.lam[lane] = static_cast<uint8_t>(lam);  // 64 coefficients
+      // bounded-distance mode for the PGZ / Euklid tags: locator degree within capability
+      if (alg != CC_ALG_BM && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;
+      if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
+
+      // ---- root search: position p is in error iff lambda(alpha^-p) = 0 ----
+      uint32_t isroot[4] = {0, 0, 0, 0};
+      if (status == CC_FRAME_OK) {
+        uint32_t acc[4];
+        const uint32_t lead = W.lam[deg];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = lead;
+        for (int j = deg - 1; j >= 0; --j) {
+          const uint32_t lj = W.lam[j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = gmul_pow(acc[c], xinv[c]) ^ lj;
+        }
+        int count = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          isroot[c] = (valid[c] && acc[c] == 0) ? 1u : 0u;
+          count += __builtin_popcountll(__ballot(isroot[c] != 0));
+        }
+        nerr = count;
+        if (count != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
+      }
+
+      // ---- error values ----
+      uint32_t yv[4] = {1, 1, 1, 1};  // bch.h:80-83
+      if (status == CC_FRAME_OK && is_rs) {
+        // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg  (S(x) lambda(x) mod x^deg)
+        uint32_t om = 0;
+        for (int m = 0; m <= deg; ++m) {
+          const uint32_t lm = W.lam[m];
+          const uint32_t s = (lane >= m && lane < deg && lane - m < t2) ? W.S[lane - m] : 0u;
+          om ^= gmul(lm, s);
+        }
+        W.om[lane] = static_cast<uint8_t>(om);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          // numerator omega(X^-1), denominator lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+          uint32_t num = 0, den = 0;
+          for (int j = deg - 1; j >= 0; --j) num = gmul_pow(num, xinv[c]) ^ W.om[j];
+          const uint32_t x2 = (2 * xinv[c]) % static_cast<uint32_t>(nn);
+          const int mtop = (deg & 1) ? deg : deg - 1;
+          for (int m = mtop; m >= 1; m -= 2) den = gmul_pow(den, x2) ^ W.lam[m];
+          yv[c] = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
+        }
+      }
+
+      // ---- verify: syndromes of the error pattern must equal the received syndromes (cyclic.h:243-248) ----
+      if (status == CC_FRAME_OK) {
+        uint32_t ly[4], ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          corr[c] = isroot[c] ? yv[c] : 0u;
+          ly[c] = lg[corr[c]];
+          ev[c] = e0[c];
+        }
+        uint32_t mismatch = 0;
+        for (int j0 = 0; j0 < t2; j0 += 4) {
+          uint32_t packed = 0, want = 0;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            uint32_t term = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              term ^= corr[c] ? ex[ly[c] + ev[c]] : 0u;
+              ev[c] += dstep[c];
+              ev[c] = ev[c] >= static_cast<uint32_t>(nn) ? ev[c] - nn : ev[c];
+            }
+            if (j0 + jj < t2) {
+              packed |= term << (8 * jj);
+              want |= static_cast<uint32_t>(W.S[j0 + jj]) << (8 * jj);
+            }
+          }
+          mismatch |= bcast63(wave_xor(packed)) ^ want;
+        }
+        if (mismatch != 0) status = CC_FRAME_RECHECK;
+      }
+    }
+
+    // ---- store ----
+    const bool ok = status == CC_FRAME_OK;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (valid[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
+    if (lane == 0) {
+      if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
+      if (status_out) status_out[frame] = status;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                     const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                     hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  const unsigned long long blocks_needed = (B + 3) / 4;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;
+  const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
+  const unsigned long long Bq = B;
+  if (float_in)
+    hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_in,
+                       d_er, d_er_off, d_out, d_nerr, d_status, Bq);
+  else
+    hipLaunchKernelGGL(algebraic_kernel<false>, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm,
+                       d_in, d_er, d_er_off, d_out, d_nerr, d_status, Bq);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "algebraic kernel launch");
+  return CC_OK;
+}
+
+}  // namespace ccamd

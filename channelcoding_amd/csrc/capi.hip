@@ -226,6 +226,11 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
   a.q = static_cast<int>(t.q);
   CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_alg), sizeof a));
   CC_HIP_TRY(hipMemcpy(code->d_alg, &a, sizeof a, hipMemcpyHostToDevice));
+  if (desc->coding == CC_CODING_DIVISION) {
+    const std::vector<uint8_t> pt = build_parity_table(*code->field, t);
+    CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_parity), pt.size()));
+    CC_HIP_TRY(hipMemcpy(code->d_parity, pt.data(), pt.size(), hipMemcpyHostToDevice));
+  }
 
   *out = code.release();
   return CC_OK;
@@ -237,6 +242,7 @@ void cc_code_destroy(cc_code *code) {
     DeviceGuard guard(code->device);
     if (code->d_colmask) (void)hipFree(code->d_colmask);
     if (code->d_emask) (void)hipFree(code->d_emask);
+    if (code->d_parity) (void)hipFree(code->d_parity);
     if (code->d_alg) (void)hipFree(code->d_alg);
   }
   delete code;
@@ -332,6 +338,156 @@ int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t 
   return CC_OK;
 }
 
+
+/* ------------------------------ hard decode ------------------------------ */
+
+static int hard_supported(const cc_code *code, bool erasures) {
+  if (code->soft) {
+    set_last_error("code was created with a min-sum algorithm; use cc_correct_soft_batch");
+    return CC_ERR_INVALID_ARGUMENT;
+  }
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  if (code->tab.family == CC_FAMILY_RS && (code->desc.mu != 1 || code->desc.step != 1)) {
+    set_last_error("RS error values on the device assume roots alpha^1..alpha^2t (mu = step = 1), as rs.h:55-69 does");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
+    // RS: the reference throws std::runtime_error (hard_decision.h:66-68); BCH: two-trial trick bch.h:97-149
+    set_last_error("PGZ with erasures is not available on the device path");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (erasures && code->desc.algorithm == CC_ALG_EUKLID) {
+    // Without erasures Euklid == bounded-distance decoding == BM with a degree bound (bit-exact, tested).
+    // With erasures the reference's stopping rule deg r < (2t+rho)/2 (hard_decision.h:181-186) selects a
+    // different locator than BM once the error count exceeds the capability, so the device path would not be
+    // bit-exact there; use berlekamp_massey_tag for erasure decoding.
+    set_last_error("Euklid with erasures is not available on the device path; use the BM tag");
+    return CC_ERR_UNSUPPORTED;
+  }
+  return CC_OK;
+}
+
+int cc_correct_hard_batch_dev(const cc_code *code, const uint8_t *d_in, const uint16_t *d_erasures,
+                              const uint32_t *d_erasure_offsets, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status,
+                              size_t B, void *stream) {
+  if (!code || (B && (!d_in || !d_out))) return CC_ERR_INVALID_ARGUMENT;
+  if ((d_erasures == nullptr) != (d_erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = hard_supported(code, d_erasures != nullptr);
+  if (rc != CC_OK) return rc;
+  DeviceGuard guard(code->device);
+  return launch_algebraic(code, false, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
+                          static_cast<hipStream_t>(stream));
+}
+
+int cc_correct_hard_f32_batch_dev(const cc_code *code, const float *d_in, uint8_t *d_out, int32_t *d_nerr,
+                                  int32_t *d_status, size_t B, void *stream) {
+  if (!code || (B && (!d_in || !d_out))) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = hard_supported(code, false);
+  if (rc != CC_OK) return rc;
+  DeviceGuard guard(code->device);
+  return launch_algebraic(code, true, d_in, nullptr, nullptr, d_out, d_nerr, d_status, B,
+                          static_cast<hipStream_t>(stream));
+}
+
+static int hard_host(const cc_code *code, bool float_in, const void *in, const uint16_t *erasures,
+                     const uint32_t *erasure_offsets, uint8_t *out, int32_t *nerr, int32_t *status, size_t B) {
+  if (!code || (B && (!in || !out))) return CC_ERR_INVALID_ARGUMENT;
+  if ((erasures == nullptr) != (erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = hard_supported(code, erasures != nullptr);
+  if (rc != CC_OK) return rc;
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n;
+  if (!float_in) {  // Element(v) throws for v outside the field, galois.h:149-152
+    const uint8_t *b = static_cast<const uint8_t *>(in);
+    const uint8_t mask = static_cast<uint8_t>(~code->tab.n);
+    for (size_t i = 0; i < B * n; ++i)
+      if (b[i] & mask) return CC_ERR_NOT_IN_FIELD;
+  }
+  DeviceGuard guard(code->device);
+  const size_t esz = float_in ? sizeof(float) : 1;
+  DevBuf<uint8_t> d_in, d_out;
+  DevBuf<uint16_t> d_er;
+  DevBuf<uint32_t> d_off;
+  DevBuf<int32_t> d_nerr, d_status;
+  CC_HIP_TRY(d_in.alloc(B * n * esz));
+  CC_HIP_TRY(d_out.alloc(B * n));
+  CC_HIP_TRY(d_nerr.alloc(B));
+  CC_HIP_TRY(d_status.alloc(B));
+  CC_HIP_TRY(hipMemcpy(d_in.p, in, B * n * esz, hipMemcpyHostToDevice));
+  if (erasures) {
+    const size_t ne = erasure_offsets[B];
+    for (size_t e = 0; e < ne; ++e)
+      if (erasures[e] >= n) return CC_ERR_INVALID_ARGUMENT;
+    CC_HIP_TRY(d_er.alloc(ne + 1));
+    CC_HIP_TRY(d_off.alloc(B + 1));
+    if (ne) CC_HIP_TRY(hipMemcpy(d_er.p, erasures, ne * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CC_HIP_TRY(hipMemcpy(d_off.p, erasure_offsets, (B + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  const int lrc = launch_algebraic(code, float_in, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr);
+  if (lrc != CC_OK) return lrc;
+  CC_HIP_TRY(hipDeviceSynchronize());
+  CC_HIP_TRY(hipMemcpy(out, d_out.p, B * n, hipMemcpyDeviceToHost));
+  if (nerr) CC_HIP_TRY(hipMemcpy(nerr, d_nerr.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (status) CC_HIP_TRY(hipMemcpy(status, d_status.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+int cc_correct_hard_batch(const cc_code *code, const uint8_t *in, const uint16_t *erasures,
+                          const uint32_t *erasure_offsets, uint8_t *out, int32_t *nerr, int32_t *status, size_t B) {
+  return hard_host(code, false, in, erasures, erasure_offsets, out, nerr, status, B);
+}
+
+int cc_correct_hard_f32_batch(const cc_code *code, const float *in, uint8_t *out, int32_t *nerr, int32_t *status,
+                              size_t B) {
+  return hard_host(code, true, in, nullptr, nullptr, out, nerr, status, B);
+}
+
+/* ------------------------------ encode / extract ------------------------------ */
+
+int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, void *stream) {
+  if (!code || (B && (!d_msg || !d_cw))) return CC_ERR_INVALID_ARGUMENT;
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  DeviceGuard guard(code->device);
+  return launch_encode(code, d_msg, d_cw, B, static_cast<hipStream_t>(stream));
+}
+
+int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, void *stream) {
+  if (!code || (B && (!d_cw || !d_msg))) return CC_ERR_INVALID_ARGUMENT;
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  DeviceGuard guard(code->device);
+  return launch_extract(code, d_cw, d_msg, B, static_cast<hipStream_t>(stream));
+}
+
+static int byte_map_host(const cc_code *code, bool encode, const uint8_t *src, uint8_t *dst, size_t B) {
+  if (!code || (B && (!src || !dst))) return CC_ERR_INVALID_ARGUMENT;
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n, l = code->tab.l;
+  const size_t in_w = encode ? l : n, out_w = encode ? n : l;
+  if (encode) {  // Element(e) throws for values outside the field, galois.h:149-152 via cyclic.h:300-301
+    const uint8_t mask = static_cast<uint8_t>(~code->tab.n);
+    for (size_t i = 0; i < B * in_w; ++i)
+      if (src[i] & mask) return CC_ERR_NOT_IN_FIELD;
+  }
+  DeviceGuard guard(code->device);
+  DevBuf<uint8_t> d_src, d_dst;
+  CC_HIP_TRY(d_src.alloc(B * in_w));
+  CC_HIP_TRY(d_dst.alloc(B * out_w));
+  CC_HIP_TRY(hipMemcpy(d_src.p, src, B * in_w, hipMemcpyHostToDevice));
+  const int rc = encode ? launch_encode(code, d_src.p, d_dst.p, B, nullptr) : launch_extract(code, d_src.p, d_dst.p, B, nullptr);
+  if (rc != CC_OK) return rc;
+  CC_HIP_TRY(hipDeviceSynchronize());
+  CC_HIP_TRY(hipMemcpy(dst, d_dst.p, B * out_w, hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+int cc_encode_batch(const cc_code *code, const uint8_t *msg, uint8_t *cw, size_t B) {
+  return byte_map_host(code, true, msg, cw, B);
+}
+int cc_extract_batch(const cc_code *code, const uint8_t *cw, uint8_t *msg, size_t B) {
+  return byte_map_host(code, false, cw, msg, B);
+}
+
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
                    uint32_t *threads_per_workgroup, uint32_t *lds_bytes) {
   if (!code) return CC_ERR_INVALID_ARGUMENT;
@@ -352,28 +508,6 @@ static int not_yet(const char *what) {
   return CC_ERR_UNSUPPORTED;
 }
 
-int cc_encode_batch(const cc_code *, const uint8_t *, uint8_t *, size_t) { return not_yet("cc_encode_batch"); }
-int cc_encode_batch_dev(const cc_code *, const uint8_t *, uint8_t *, size_t, void *) {
-  return not_yet("cc_encode_batch_dev");
-}
-int cc_correct_hard_batch(const cc_code *, const uint8_t *, const uint16_t *, const uint32_t *, uint8_t *, int32_t *,
-                          int32_t *, size_t) {
-  return not_yet("cc_correct_hard_batch");
-}
-int cc_correct_hard_batch_dev(const cc_code *, const uint8_t *, const uint16_t *, const uint32_t *, uint8_t *,
-                              int32_t *, int32_t *, size_t, void *) {
-  return not_yet("cc_correct_hard_batch_dev");
-}
-int cc_correct_hard_f32_batch(const cc_code *, const float *, uint8_t *, int32_t *, int32_t *, size_t) {
-  return not_yet("cc_correct_hard_f32_batch");
-}
-int cc_correct_hard_f32_batch_dev(const cc_code *, const float *, uint8_t *, int32_t *, int32_t *, size_t, void *) {
-  return not_yet("cc_correct_hard_f32_batch_dev");
-}
-int cc_extract_batch(const cc_code *, const uint8_t *, uint8_t *, size_t) { return not_yet("cc_extract_batch"); }
-int cc_extract_batch_dev(const cc_code *, const uint8_t *, uint8_t *, size_t, void *) {
-  return not_yet("cc_extract_batch_dev");
-}
 int cc_mc_run_dev(const cc_code *, double, uint64_t, uint64_t, size_t, int, uint64_t *, void *) {
   return not_yet("cc_mc_run_dev");
 }

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/channelcoding_amd.h"
 #include "galois.hpp"
@@ -51,6 +52,7 @@ struct cc_code {
   bool soft = false;
   ccamd::MinSumGeometry geo;
   uint32_t *d_colmask = nullptr;
+  uint8_t *d_parity = nullptr;  // k x l table of x^(k+j) mod g (division_tag encoder)
   uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
   ccamd::AlgebraicTables *d_alg = nullptr;
   ccamd::AlgebraicTables h_alg;
@@ -80,6 +82,14 @@ const char *minsum_reg_name(const cc_code *code);
 int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                       size_t B, hipStream_t stream);
+// algebraic.hip
+int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                     const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                     hipStream_t stream);
+// encode.hip
+std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t);
+int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
+int launch_extract(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, hipStream_t stream);
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds);
 

@@ -1,0 +1,87 @@
+"""GPU tests of the batched encoder / message extraction (cc_encode_batch, cc_extract_batch) and
+full-size round-trip properties of the whole chain (encode -> corrupt -> decode)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from checkers import BCH, REF_CODES, RS, Oracle
+
+import channelcoding_amd as cc
+from channelcoding_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def make_code(cid, tag=None, **kw):
+    fam, q, t = REF_CODES[cid]
+    cls = cc.primitive_bch if fam == BCH else cc.rs
+    return cls(q, cc.errors(t), tag or cc.berlekamp_massey_tag(), **kw)
+
+
+@pytest.mark.parametrize("cid", G.HARD_CIDS)
+def test_encode_golden(cid):
+    d = G.load("encode", cid)
+    code = make_code(cid)
+    cw = code.encode_batch(d["msg"])
+    assert np.array_equal(cw, d["cw"])
+    assert np.array_equal(code.extract_batch(cw), d["msg"])
+    assert np.array_equal(code.encode(d["msg"][3]), d["cw"][3])  # single-frame API
+
+
+@pytest.mark.parametrize("cid", [0, 5, 6, 9, 10])
+def test_encode_multiplication_tag(cid):
+    """cyclic.h:29-33: c = a * g."""
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t, coding=1)
+    code = make_code(cid, coding="multiplication")
+    rng = np.random.default_rng(70 + cid)
+    hi = 2 if fam == BCH else 1 << q
+    msg = rng.integers(0, hi, (300, o.l)).astype(np.uint8)
+    msg[0] = 0
+    assert np.array_equal(code.encode_batch(msg), o.encode(msg))
+
+
+def test_encode_errors():
+    code = make_code(9)
+    with pytest.raises(cc.CcError) as e:
+        code.encode_batch(np.zeros((2, 8), np.uint8))  # "Source code word has wrong length", cyclic.h:291-296
+    assert e.value.status == capi.ERR_LENGTH
+    with pytest.raises(cc.CcError) as e:
+        code.encode_batch(np.full((1, 9), 200, np.uint8))
+    assert e.value.status == capi.ERR_NOT_IN_FIELD
+    assert code.encode_batch(np.zeros((0, 9), np.uint8)).shape == (0, 15)
+
+
+@pytest.mark.parametrize("cid,log2b", [(6, 20), (10, 18)])
+def test_full_size_roundtrip(cid, log2b):
+    """BASELINE sizes through size-independent properties, all on device:
+    every codeword has zero syndromes (decoder returns it untouched with nerr = 0);
+    encode -> <= t random symbol errors -> decode returns the transmitted word and the error count;
+    extract(encode(m)) == m; encoding is linear."""
+    import torch
+    fam, q, t = REF_CODES[cid]
+    code = make_code(cid)
+    B = 1 << log2b
+    g = torch.Generator(device="cuda")
+    g.manual_seed(cid)
+    hi = 2 if fam == BCH else 1 << q
+    msg = torch.randint(0, hi, (B, code.l), dtype=torch.uint8, device="cuda", generator=g)
+    cw = code.encode_batch(msg)
+    assert torch.equal(code.extract_batch(cw), msg)
+    clean = code.correct_batch(cw)
+    assert int((clean["status"] != 0).sum()) == 0 and int(clean["nerr"].abs().sum()) == 0
+    assert torch.equal(clean["out"], cw)
+    # linearity: enc(a) ^ enc(b) == enc(a ^ b)
+    msg2 = torch.randint(0, hi, (B, code.l), dtype=torch.uint8, device="cuda", generator=g)
+    assert torch.equal(cw ^ code.encode_batch(msg2), code.encode_batch(msg ^ msg2))
+    # <= t errors at distinct random positions, non-zero values
+    nerr = torch.randint(0, t + 1, (B,), device="cuda", generator=g)
+    perm = torch.rand((B, code.n), device="cuda", generator=g).argsort(dim=1)[:, :t]
+    vals = torch.randint(1, hi, (B, t), dtype=torch.uint8, device="cuda", generator=g)
+    vals = torch.where(torch.arange(t, device="cuda")[None, :] < nerr[:, None], vals, torch.zeros_like(vals))
+    rx = cw.clone()
+    rx.scatter_(1, perm, rx.gather(1, perm) ^ vals)
+    res = code.correct_batch(rx)
+    assert int((res["status"] != 0).sum()) == 0
+    assert torch.equal(res["out"], cw)
+    assert torch.equal(res["nerr"], nerr.to(torch.int32))
