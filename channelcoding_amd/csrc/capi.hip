@@ -243,6 +243,7 @@ void cc_code_destroy(cc_code *code) {
     if (code->d_colmask) (void)hipFree(code->d_colmask);
     if (code->d_emask) (void)hipFree(code->d_emask);
     if (code->d_parity) (void)hipFree(code->d_parity);
+    if (code->mc) mc_workspace_free(code->mc);
     if (code->d_alg) (void)hipFree(code->d_alg);
   }
   delete code;
@@ -488,6 +489,39 @@ int cc_extract_batch(const cc_code *code, const uint8_t *cw, uint8_t *msg, size_
   return byte_map_host(code, false, cw, msg, B);
 }
 
+/* ------------------------------ Monte-Carlo ------------------------------ */
+
+static int mc_supported(const cc_code *code) {
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  if (code->tab.family != CC_FAMILY_BCH) {
+    set_last_error("the BPSK/AWGN Monte-Carlo channel is defined for binary (BCH) codes");
+    return CC_ERR_UNSUPPORTED;
+  }
+  return CC_OK;
+}
+
+int cc_mc_run_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                  int random_codewords, uint64_t *d_counters, void *stream) {
+  if (!code || !d_counters) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = mc_supported(code);
+  if (rc != CC_OK) return rc;
+  if (random_codewords && code->desc.coding != CC_CODING_DIVISION && code->desc.coding != CC_CODING_MULTIPLICATION)
+    return CC_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard(code->device);
+  return mc_run(const_cast<cc_code *>(code), ebno_db, seed, first_frame, frames, random_codewords, d_counters,
+                static_cast<hipStream_t>(stream));
+}
+
+int cc_awgn_llr_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                    int random_codewords, float *d_llr, uint8_t *d_sent, void *stream) {
+  if (!code || (frames && !d_llr)) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = mc_supported(code);
+  if (rc != CC_OK) return rc;
+  DeviceGuard guard(code->device);
+  return mc_awgn(const_cast<cc_code *>(code), ebno_db, seed, first_frame, frames, random_codewords, d_llr, d_sent,
+                 static_cast<hipStream_t>(stream));
+}
+
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
                    uint32_t *threads_per_workgroup, uint32_t *lds_bytes) {
   if (!code) return CC_ERR_INVALID_ARGUMENT;
@@ -501,19 +535,7 @@ int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames
   return CC_OK;
 }
 
-/* ---- entry points whose kernels land in the next milestones: present in the
- *      ABI, fail loudly (never a CPU fallback) until then ---- */
-static int not_yet(const char *what) {
-  set_last_error(std::string(what) + ": device kernel not built into this library version");
-  return CC_ERR_UNSUPPORTED;
-}
 
-int cc_mc_run_dev(const cc_code *, double, uint64_t, uint64_t, size_t, int, uint64_t *, void *) {
-  return not_yet("cc_mc_run_dev");
-}
-int cc_awgn_llr_dev(const cc_code *, double, uint64_t, uint64_t, size_t, int, float *, uint8_t *, void *) {
-  return not_yet("cc_awgn_llr_dev");
-}
 
 }  // extern "C"
 #pragma GCC visibility pop

@@ -44,6 +44,11 @@ struct AlgebraicTables {
 
 }  // namespace ccamd
 
+namespace ccamd {
+struct McWorkspace;
+void mc_workspace_free(McWorkspace *w);
+}  // namespace ccamd
+
 struct cc_code {
   cc_desc desc;
   int device = 0;
@@ -56,7 +61,7 @@ struct cc_code {
   uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
   ccamd::AlgebraicTables *d_alg = nullptr;
   ccamd::AlgebraicTables h_alg;
-  uint32_t *d_zero_offsets = nullptr;  // scratch: unused
+  mutable ccamd::McWorkspace *mc = nullptr;  // lazily allocated Monte-Carlo chunk buffers
   int num_cus = 256;
   bool force_generic = false;  // CC_AMD_FORCE_GENERIC=1: A/B the generic kernel against the fast one
   std::string name;
@@ -90,6 +95,11 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
 std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t);
 int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
 int launch_extract(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, hipStream_t stream);
+// mc.hip (Monte-Carlo calls on one handle must be issued on one stream at a time: they share a workspace)
+int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,
+           uint64_t *d_counters, hipStream_t stream);
+int mc_awgn(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,
+            float *d_llr, uint8_t *d_sent, hipStream_t stream);
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds);
 

@@ -1,0 +1,274 @@
+// mc.hip -- batched AWGN Monte-Carlo on the device (replaces the per-frame loop of
+// awgn_simulation::operator(), src/simulation/simulation.c++:95-150).
+//
+//   channel   y = (1 - 2c) + sigma * N(0,1),  sigma = 1/sqrt(2 R 10^(EbN0/10))  (simulation.c++:83-85,
+//             :113-125; the reference transmits the all-zero word, i.e. N(1, sigma))
+//   noise     Philox4x32-10, key = (seed_lo, seed_hi), counter = (frame_lo, frame_hi, quad, domain);
+//             quad q yields the four normals of symbols 4q..4q+3 via two Box-Muller pairs.  A frame's
+//             noise depends only on (seed, global frame index): results are independent of how frames
+//             are sharded over GPUs or chunked inside a call.
+//   messages  (random_codewords) l bits per frame from the same generator, domain 1, then the device
+//             encoder.
+//   counters  word / bit / failure / undetected / channel-bit errors and the iteration histogram,
+//             accumulated in LDS per workgroup and flushed with one 64-bit atomic per counter.
+#include <cmath>
+#include <mutex>
+
+#include "cc_internal.hpp"
+
+namespace ccamd {
+namespace {
+
+struct Philox {
+  uint32_t c[4];
+};
+
+__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += W0;
+    k1 += W1;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1) {
+  const float u1 = (static_cast<float>(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+  const float u2 = static_cast<float>(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+  const float r = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.28318530717958647692f * u2, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+__global__ void __launch_bounds__(256)
+random_bits_kernel(uint8_t *__restrict__ msg, int l, unsigned long long first_frame, unsigned long long frames,
+                   uint32_t k0, uint32_t k1) {
+  const int quads = (l + 127) / 128;  // one Philox call yields 128 bits
+  const unsigned long long total = frames * quads;
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += stride) {
+    const unsigned long long f = idx / quads;
+    const int qd = static_cast<int>(idx - f * quads);
+    const unsigned long long gf = first_frame + f;
+    const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), qd, 1u, k0, k1);
+    for (int b = 0; b < 128; ++b) {
+      const int j = qd * 128 + b;
+      if (j < l) msg[f * l + j] = (p.c[b >> 5] >> (b & 31)) & 1u;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, unsigned long long first_frame,
+            unsigned long long frames, float sigma, uint32_t k0, uint32_t k1) {
+  const int quads = (n + 3) / 4;
+  const unsigned long long total = frames * quads;
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += stride) {
+    const unsigned long long f = idx / quads;
+    const int qd = static_cast<int>(idx - f * quads);
+    const unsigned long long gf = first_frame + f;
+    const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), qd, 0u, k0, k1);
+    float z[4];
+    box_muller(p.c[0], p.c[1], z[0], z[1]);
+    box_muller(p.c[2], p.c[3], z[2], z[3]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int j = 4 * qd + s;
+      if (j < n) {
+        const float x = (sent != nullptr && sent[f * n + j]) ? -1.0f : 1.0f;  // BPSK 0 -> +1
+        llr[f * n + j] = x + sigma * z[s];
+      }
+    }
+  }
+}
+
+// one wave per frame: compares the decoder output with the transmitted word
+__global__ void __launch_bounds__(256)
+count_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ sent, const float *__restrict__ llr,
+             const uint16_t *__restrict__ iters, const int32_t *__restrict__ status, int n, unsigned iterations,
+             unsigned long long frames, unsigned long long *__restrict__ counters) {
+  __shared__ unsigned int acc[CC_MC_NCOUNTERS];
+  if (threadIdx.x < CC_MC_NCOUNTERS) acc[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < frames; f += nwaves) {
+    unsigned biterr = 0, cherr = 0;
+    for (int j = lane; j < n; j += 64) {
+      const unsigned s = sent ? sent[f * n + j] : 0u;
+      biterr += (hard[f * n + j] != s);
+      cherr += ((llr[f * n + j] < 0.0f ? 1u : 0u) != s);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+      biterr += __shfl_xor(biterr, m, 64);
+      cherr += __shfl_xor(cherr, m, 64);
+    }
+    if (lane == 0) {
+      const bool failed = status[f] != CC_FRAME_OK;
+      atomicAdd(&acc[CC_MC_FRAMES], 1u);
+      atomicAdd(&acc[CC_MC_BIT_ERRORS], biterr);
+      atomicAdd(&acc[CC_MC_CHANNEL_BIT_ERRORS], cherr);
+      if (failed || biterr) atomicAdd(&acc[CC_MC_WORD_ERRORS], 1u);  // simulation.c++:128-135
+      if (failed) atomicAdd(&acc[CC_MC_FAILURES], 1u);
+      if (!failed && biterr) atomicAdd(&acc[CC_MC_UNDETECTED], 1u);
+      if (iters) {
+        const unsigned it = iters[f];
+        const unsigned run = failed ? iterations : it + 1;  // iterations executed
+        atomicAdd(&acc[CC_MC_ITER_SUM], run);
+        if (!failed && it <= 55) atomicAdd(&acc[CC_MC_ITER_HIST + it], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CC_MC_NCOUNTERS && acc[threadIdx.x])
+    atomicAdd(&counters[threadIdx.x], static_cast<unsigned long long>(acc[threadIdx.x]));
+}
+
+int grid_for(const cc_code *code, unsigned long long items_per_thread_total) {
+  const unsigned long long want = (items_per_thread_total + 255) / 256;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
+  return static_cast<int>(want < max_grid ? (want ? want : 1) : max_grid);
+}
+
+}  // namespace
+
+struct McWorkspace {
+  std::mutex lock;
+  size_t chunk = 0;
+  float *llr = nullptr;
+  uint8_t *sent = nullptr, *msg = nullptr, *hard = nullptr;
+  uint16_t *iters = nullptr;
+  int32_t *status = nullptr, *nerr = nullptr;
+  ~McWorkspace() {
+    for (void *p : {static_cast<void *>(llr), static_cast<void *>(sent), static_cast<void *>(msg),
+                    static_cast<void *>(hard), static_cast<void *>(iters), static_cast<void *>(status),
+                    static_cast<void *>(nerr)})
+      if (p) (void)hipFree(p);
+  }
+};
+
+void mc_workspace_free(McWorkspace *w) { delete w; }
+
+static int ensure_workspace(cc_code *code, size_t chunk) {
+  if (!code->mc) code->mc = new McWorkspace();
+  McWorkspace &w = *code->mc;
+  if (w.chunk >= chunk) return CC_OK;
+  const size_t n = code->tab.n, l = code->tab.l;
+  for (void **p : {reinterpret_cast<void **>(&w.llr), reinterpret_cast<void **>(&w.sent),
+                   reinterpret_cast<void **>(&w.msg), reinterpret_cast<void **>(&w.hard),
+                   reinterpret_cast<void **>(&w.iters), reinterpret_cast<void **>(&w.status),
+                   reinterpret_cast<void **>(&w.nerr)})
+    if (*p) {
+      (void)hipFree(*p);
+      *p = nullptr;
+    }
+  w.chunk = 0;
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.llr), chunk * n * sizeof(float)));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.sent), chunk * n));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.msg), chunk * l));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.hard), chunk * n));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.iters), chunk * sizeof(uint16_t)));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.status), chunk * sizeof(int32_t)));
+  CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w.nerr), chunk * sizeof(int32_t)));
+  w.chunk = chunk;
+  return CC_OK;
+}
+
+// writes y (and the transmitted words when d_sent != nullptr) for frames [first, first + frames)
+int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
+                int random_codewords, float *d_llr, uint8_t *d_sent, uint8_t *d_msg_scratch, hipStream_t stream) {
+  if (frames == 0) return CC_OK;
+  const int n = static_cast<int>(code->tab.n), l = static_cast<int>(code->tab.l);
+  const float sigma = static_cast<float>(cc_sigma(code, ebno_db));  // normal_distribution<float>(1.0, float(sigma))
+  const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+  const uint8_t *sent = nullptr;
+  if (random_codewords) {
+    if (!d_sent || !d_msg_scratch) return CC_ERR_INVALID_ARGUMENT;
+    const unsigned long long items = static_cast<unsigned long long>(frames) * ((l + 127) / 128);
+    hipLaunchKernelGGL(random_bits_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_msg_scratch, l,
+                       static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), k0, k1);
+    const int rc = launch_encode(code, d_msg_scratch, d_sent, frames, stream);
+    if (rc != CC_OK) return rc;
+    sent = d_sent;
+  } else if (d_sent) {
+    CC_HIP_TRY(hipMemsetAsync(d_sent, 0, frames * static_cast<size_t>(n), stream));
+  }
+  const unsigned long long items = static_cast<unsigned long long>(frames) * ((n + 3) / 4);
+  hipLaunchKernelGGL(awgn_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n,
+                     static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
+                     k1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "awgn kernel launch");
+  return CC_OK;
+}
+
+int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,
+           uint64_t *d_counters, hipStream_t stream) {
+  if (frames == 0) return CC_OK;
+  const size_t chunk_max = size_t(1) << 16;
+  const size_t chunk = frames < chunk_max ? frames : chunk_max;
+  if (!code->mc) code->mc = new McWorkspace();
+  std::lock_guard<std::mutex> guard(code->mc->lock);
+  int rc = ensure_workspace(code, chunk);
+  if (rc != CC_OK) return rc;
+  McWorkspace &w = *code->mc;
+  const int n = static_cast<int>(code->tab.n);
+  for (size_t done = 0; done < frames; done += chunk) {
+    const size_t m = frames - done < chunk ? frames - done : chunk;
+    rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, random_codewords, w.llr, w.sent, w.msg, stream);
+    if (rc != CC_OK) return rc;
+    if (code->soft)
+      rc = launch_minsum(code, w.llr, nullptr, nullptr, w.hard, nullptr, w.iters, w.status, m, stream);
+    else
+      rc = launch_algebraic(code, true, w.llr, nullptr, nullptr, w.hard, w.nerr, w.status, m, stream);
+    if (rc != CC_OK) return rc;
+    const unsigned long long blocks = (m + 3) / 4;
+    const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
+    hipLaunchKernelGGL(count_kernel, dim3(static_cast<int>(blocks < max_grid ? blocks : max_grid)), dim3(256), 0, stream,
+                       w.hard, w.sent, w.llr, code->soft ? w.iters : nullptr, w.status, n, code->desc.iterations,
+                       static_cast<unsigned long long>(m), reinterpret_cast<unsigned long long *>(d_counters));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "count kernel launch");
+  }
+  return CC_OK;
+}
+
+
+// cc_awgn_llr_dev: channel only, chunked so that the message scratch stays bounded
+int mc_awgn(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,
+            float *d_llr, uint8_t *d_sent, hipStream_t stream) {
+  if (frames == 0) return CC_OK;
+  if (!random_codewords) return launch_awgn(code, ebno_db, seed, first_frame, frames, 0, d_llr, d_sent, nullptr, stream);
+  const size_t chunk_max = size_t(1) << 16;
+  const size_t chunk = frames < chunk_max ? frames : chunk_max;
+  if (!code->mc) code->mc = new McWorkspace();
+  std::lock_guard<std::mutex> guard(code->mc->lock);
+  int rc = ensure_workspace(code, chunk);
+  if (rc != CC_OK) return rc;
+  McWorkspace &w = *code->mc;
+  const size_t n = code->tab.n;
+  for (size_t done = 0; done < frames; done += chunk) {
+    const size_t m = frames - done < chunk ? frames - done : chunk;
+    uint8_t *sent = d_sent ? d_sent + done * n : w.sent;
+    rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, 1, d_llr + done * n, sent, w.msg, stream);
+    if (rc != CC_OK) return rc;
+  }
+  return CC_OK;
+}
+
+}  // namespace ccamd
