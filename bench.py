@@ -30,6 +30,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 measured attainable
 
 
+def measured_traffic(kernel, batch_log2):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE; separate passes).  None when no measurement exists for this kernel and batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_minsum.json")) as f:
+            t = json.load(f)
+        if t["kernel"] == kernel and t["batch_log2"] == batch_log2:
+            return t["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(y_sample, iterations, budget_s=20.0):
     """Reference CPU path on this box's host cores (1 thread: the reference decodes frames sequentially,
     src/simulation/simulation.c++:124-136).  Same frames as the GPU workload, stop rule O2."""
@@ -170,7 +183,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name.value.decode(), args.batch_log2),
                 "kernel": name.value.decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bytes_per_frame,
                 "note": "path is VALU-issue bound, not HBM bound (SURVEY F4): %.1f min-sum iterations per frame on average"
                         % mean_iters,
