@@ -353,6 +353,35 @@ hipError_t launch_reg(const MinSumParams &p, const uint64_t *emask, int grid, hi
   return hipGetLastError();
 }
 
+// (k, C, rows per batch) combinations instantiated below.  k*C <= 96 keeps the kernel at 4 waves/SIMD.
+struct RegGeometry {
+  int K, C, RB;
+};
+constexpr RegGeometry kRegGeometries[] = {
+    {24, 4, 4},  // BCH(255,231) t=3   (headline)
+    {16, 4, 4},  // BCH(255,239) t=2
+    {8, 4, 4},   // BCH(255,247) t=1
+    {32, 4, 4},  // BCH(255,223) t=4   (128 slots: 2-3 waves/SIMD)
+    {14, 2, 7},  // BCH(127,113) t=2
+    {21, 2, 7},  // BCH(127,106) t=3
+    {7, 2, 7},   // BCH(127,120) t=1
+    {18, 1, 6},  // BCH(63,45)   t=3
+    {24, 1, 6},  // BCH(63,39)   t=4
+    {12, 1, 6},  // BCH(63,51)   t=2
+    {6, 1, 6},   // BCH(63,57)   t=1
+};
+
+int rows_per_batch(int K, int C) {
+  static const int env = [] {
+    const char *e = std::getenv("CC_AMD_RB");  // tuning knob for the headline geometry only
+    return e ? std::atoi(e) : 0;
+  }();
+  if (K == 24 && C == 4 && (env == 2 || env == 3 || env == 6 || env == 8 || env == 12)) return env;
+  for (const RegGeometry &g : kRegGeometries)
+    if (g.K == K && g.C == C) return g.RB;
+  return 0;
+}
+
 }  // namespace
 
 // returns true when a register-resident instantiation exists for this code + algorithm
@@ -363,25 +392,13 @@ bool minsum_reg_supported(const cc_code *code) {
   const float a = static_cast<float>(code->desc.alpha);
   if ((alg == CC_ALG_NMS || alg == CC_ALG_2DNMS) && !(a == a && a - a == 0.0f)) return false;  // finite alpha
   if (code->geo.W != 64 || code->d_emask == nullptr) return false;
-  const int K = static_cast<int>(code->tab.k), C = code->geo.C;
-  return (K == 24 && C == 4) || (K == 18 && C == 1);
+  return rows_per_batch(static_cast<int>(code->tab.k), code->geo.C) != 0;
 }
-
-namespace {
-int rows_per_batch(int K) {
-  static const int env = [] {
-    const char *e = std::getenv("CC_AMD_RB");  // tuning knob: rows reduced together (must divide k)
-    return e ? std::atoi(e) : 0;
-  }();
-  if (env > 0 && K % env == 0) return env;
-  return K == 24 ? 4 : 6;
-}
-}  // namespace
 
 const char *minsum_reg_name(const cc_code *code) {
   const int K = static_cast<int>(code->tab.k), C = code->geo.C;
   static thread_local char buf[64];
-  std::snprintf(buf, sizeof buf, "minsum_reg_kernel<K=%d,C=%d,RB=%d>", K, C, rows_per_batch(K));
+  std::snprintf(buf, sizeof buf, "minsum_reg_kernel<K=%d,C=%d,RB=%d>", K, C, rows_per_batch(K, C));
   return buf;
 }
 
@@ -393,18 +410,26 @@ int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   hipError_t e = hipErrorInvalidValue;
-  const int rb = rows_per_batch(K);
+  const int rb = rows_per_batch(K, C);
 #define CC_GO(KK, CCC, RRB)                   \
   if (K == KK && C == CCC && rb == RRB)       \
   e = launch_reg<KK, CCC, RRB>(p, code->d_emask, grid, stream, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B)
-  CC_GO(24, 4, 12);
-  CC_GO(24, 4, 8);
-  CC_GO(24, 4, 6);
   CC_GO(24, 4, 4);
-  CC_GO(24, 4, 3);
   CC_GO(24, 4, 2);
-  CC_GO(18, 1, 9);
+  CC_GO(24, 4, 3);
+  CC_GO(24, 4, 6);
+  CC_GO(24, 4, 8);
+  CC_GO(24, 4, 12);
+  CC_GO(16, 4, 4);
+  CC_GO(8, 4, 4);
+  CC_GO(32, 4, 4);
+  CC_GO(14, 2, 7);
+  CC_GO(21, 2, 7);
+  CC_GO(7, 2, 7);
   CC_GO(18, 1, 6);
+  CC_GO(24, 1, 6);
+  CC_GO(12, 1, 6);
+  CC_GO(6, 1, 6);
 #undef CC_GO
   if (e != hipSuccess) return hip_fail(e, "minsum_reg kernel launch");
   return CC_OK;

@@ -152,3 +152,20 @@ def test_minsum_device_pointers():
     ob, oL, oit, ost = o.minsum(0, 20, y[sub], stop=O2, fast=True)
     assert np.array_equal(host["out"][sub], ob) and np.array_equal(host["L"][sub], oL)
     assert np.array_equal(host["iters"][sub], oit) and np.array_equal(host["status"][sub], ost)
+
+
+@pytest.mark.parametrize("q,t", [(8, 2), (8, 1), (8, 4), (7, 3), (7, 1), (6, 2), (6, 1), (8, 5), (7, 4)])
+def test_minsum_other_geometries(q, t):
+    """Every register-kernel instantiation (and, for (8,5)/(7,4), the generic fallback) against the oracle."""
+    o = Oracle(BCH, q, t)
+    rng = np.random.default_rng(4500 + 10 * q + t)
+    frames = 150
+    cw = o.encode(rng.integers(0, 2, (frames, o.l)).astype(np.uint8))
+    cw[:50] = 0
+    ebno = rng.choice([3.0, 5.0, 7.0], frames)
+    y = np.concatenate([awgn_llr(rng, cw[f:f + 1], o.l / o.n, ebno[f]) for f in range(frames)])
+    for v, rule in ((0, O2), (1, O2), (2, O1), (6, O2), (3, O2), (0, O0)):
+        ov, alpha, beta = REF_VARIANTS[v]
+        code = cc.primitive_bch(q, cc.errors(t), TAG[ov](12, alpha, beta), stop_rule=rule)
+        res = code.correct_batch(y, want_L=True)
+        check(res, *o.minsum(ov, 12, y, alpha, beta, rule, fast=True), tag=(q, t, v, rule))
