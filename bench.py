@@ -43,6 +43,62 @@ def measured_traffic(kernel, batch_log2):
     return None
 
 
+def secondary_workloads(torch, cc, capi, dev):
+    """The other single-GPU BASELINE configs, reported next to the headline (not part of `value`):
+    configs[1] BCH(63,45) MS<10> at 4 dB, batch 2^16; configs[3] RS(255,223) syndrome + BM + root search +
+    error values, batch 2^20, e ~ U{0..16} symbol errors."""
+    lib = capi.lib()
+    out = {}
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    sh = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    # configs[1]
+    code = cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(10))
+    B = 1 << 16
+    y = torch.empty((B, 63), dtype=torch.float32, device=dev).normal_(1.0, float(code.sigma(4.0)), generator=g)
+    hard = torch.empty((B, 63), dtype=torch.uint8, device=dev)
+    it = torch.empty(B, dtype=torch.int16, device=dev)
+    st = torch.empty(B, dtype=torch.int32, device=dev)
+    ms = timed(lambda: lib.cc_correct_soft_batch_dev(code._h, vp(y), None, None, vp(hard), None, vp(it), vp(st), B, sh))
+    out["bch63_45_ms10_4dB_2^16"] = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms,
+                                     "converged_fraction": float((st == 0).float().mean())}
+    # configs[3]
+    rs = cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag())
+    B = 1 << 20
+    msg = torch.randint(0, 256, (B, rs.l), dtype=torch.uint8, device=dev, generator=g)
+    cw = rs.encode_batch(msg)
+    nerr = torch.randint(0, 17, (B,), device=dev, generator=g)
+    perm = torch.rand((B, 255), device=dev, generator=g).argsort(dim=1)[:, :16]
+    vals = torch.randint(1, 256, (B, 16), dtype=torch.uint8, device=dev, generator=g)
+    vals = torch.where(torch.arange(16, device=dev)[None, :] < nerr[:, None], vals, torch.zeros_like(vals))
+    rx = cw.clone()
+    rx.scatter_(1, perm, rx.gather(1, perm) ^ vals)
+    del perm, vals, msg
+    outw = torch.empty_like(rx)
+    ne = torch.empty(B, dtype=torch.int32, device=dev)
+    st = torch.empty(B, dtype=torch.int32, device=dev)
+    ms = timed(lambda: lib.cc_correct_hard_batch_dev(rs._h, vp(rx), None, None, vp(outw), vp(ne), vp(st), B, sh))
+    ok = bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0
+    out["rs255_223_bm_2^20"] = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms, "all_frames_corrected": ok,
+                                "achieved_GBs": 518 * B / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_frame": 518}
+    enc_ms = timed(lambda: rs.encode_batch(cw[:, rs.k:].contiguous()))
+    out["rs255_223_encode_2^20"] = {"frames_per_s": B / (enc_ms * 1e-3), "kernel_ms": enc_ms}
+    return out
+
+
 def cpu_baseline(y_sample, iterations, budget_s=20.0):
     """Reference CPU path on this box's host cores (1 thread: the reference decodes frames sequentially,
     src/simulation/simulation.c++:124-136).  Same frames as the GPU workload, stop rule O2."""
@@ -79,6 +135,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--stop-rule", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +250,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(y[:4096].cpu().numpy(), args.iterations)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary:
+            del y, hard
+            out["secondary"] = secondary_workloads(torch, cc, capi, dev)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
