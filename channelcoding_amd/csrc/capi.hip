@@ -199,6 +199,17 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
     }
     CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
     CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (t.n == 255 && t.k <= 32 && t.row0_support.size() % 16 == 0 && t.row0_support.size() / 16 == 7) {
+      const std::vector<uint16_t> dg = build_diag_table(t, 7);
+      std::vector<uint32_t> cb(256, 0u);
+      for (unsigned j = 0; j < t.n; ++j)
+        for (unsigned i = 0; i < t.k && i <= j; ++i)
+          if (t.row0[j - i]) cb[j] |= 1u << i;
+      CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_diag), dg.size() * sizeof(uint16_t)));
+      CC_HIP_TRY(hipMemcpy(code->d_diag, dg.data(), dg.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colbits), cb.size() * sizeof(uint32_t)));
+      CC_HIP_TRY(hipMemcpy(code->d_colbits, cb.data(), cb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (g.W == 64) {
       std::vector<uint64_t> em(static_cast<size_t>(t.k) * g.C, 0ull);
       for (unsigned i = 0; i < t.k; ++i)
@@ -242,6 +253,8 @@ void cc_code_destroy(cc_code *code) {
     DeviceGuard guard(code->device);
     if (code->d_colmask) (void)hipFree(code->d_colmask);
     if (code->d_emask) (void)hipFree(code->d_emask);
+    if (code->d_diag) (void)hipFree(code->d_diag);
+    if (code->d_colbits) (void)hipFree(code->d_colbits);
     if (code->d_parity) (void)hipFree(code->d_parity);
     if (code->mc) mc_workspace_free(code->mc);
     if (code->d_alg) (void)hipFree(code->d_alg);

@@ -57,6 +57,8 @@ struct cc_code {
   bool soft = false;
   ccamd::MinSumGeometry geo;
   uint32_t *d_colmask = nullptr;
+  uint16_t *d_diag = nullptr;    // [D][16] diagonal (row-0 support) dealt to 16 lanes x D slots (minsum_diag)
+  uint32_t *d_colbits = nullptr;  // [256] per column: bit i = H[i][col]
   uint8_t *d_parity = nullptr;  // k x l table of x^(k+j) mod g (division_tag encoder)
   uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
   ccamd::AlgebraicTables *d_alg = nullptr;
@@ -87,6 +89,13 @@ const char *minsum_reg_name(const cc_code *code);
 int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                       size_t B, hipStream_t stream);
+// minsum_diag.hip
+std::vector<uint16_t> build_diag_table(const CodeTables &t, int D);
+bool minsum_diag_supported(const cc_code *code);
+const char *minsum_diag_name(const cc_code *code);
+int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
+                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
+                       size_t B, hipStream_t stream);
 // algebraic.hip
 int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,

@@ -257,6 +257,13 @@ size_t generic_lds_bytes(const cc_code *code) {
 
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds) {
+  if (minsum_diag_supported(code) && !code->force_generic) {
+    name = minsum_diag_name(code);
+    frames_per_wg = 16;
+    threads = 256;
+    lds = 4 * (4 * 272 * 12) + 1024;
+    return CC_OK;
+  }
   if (minsum_reg_supported(code)) {
     name = minsum_reg_name(code);
     frames_per_wg = 4;
@@ -286,6 +293,8 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   p.beta_d = code->desc.beta;
   p.colmask = code->d_colmask;
 
+  if (minsum_diag_supported(code) && !code->force_generic)
+    return launch_minsum_diag(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
   if (minsum_reg_supported(code) && !code->force_generic)
     return launch_minsum_reg(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 
