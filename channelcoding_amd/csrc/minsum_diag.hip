@@ -29,6 +29,10 @@
 #include "cc_internal.hpp"
 #include "wave_ops.hpp"
 
+#ifndef CC_DIAG_PIPELINE
+#define CC_DIAG_PIPELINE 1
+#endif
+
 namespace ccamd {
 namespace {
 
@@ -180,6 +184,68 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     }
 
     // ---------------- one min-sum iteration for the four resident frames ----------------
+#if CC_DIAG_PIPELINE
+    // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
+    // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
+    float2 cyq[D];
+    static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD]); });
+    static_for<K>([&](auto IR) {
+      constexpr int i = IR;
+      uint32_t m1[1], m2[1], sg[1];
+      {
+        float a1 = 0.0f, a2 = 0.0f;
+        uint32_t s = 0;
+        static_for<D>([&](auto DD) {
+          constexpr int d = DD;
+          float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
+          if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
+          const float q = e + cyq[d].y;                                       // :136,:207-209
+          R[i][d] = q;
+          const float a = __builtin_fabsf(q);
+          if constexpr (d == 0) {
+            a1 = a;
+            s = f2u(q);
+          } else if constexpr (d == 1) {
+            a2 = __builtin_fmaxf(a1, a);
+            a1 = __builtin_fminf(a1, a);
+            s ^= f2u(q);
+          } else {
+            a2 = __builtin_amdgcn_fmed3f(a1, a, a2);
+            a1 = __builtin_fminf(a1, a);
+            s ^= f2u(q);
+          }
+        });
+        m1[0] = f2u(a1);
+        m2[0] = f2u(a2);
+        sg[0] = s;
+      }
+      if constexpr (i + 1 < K)  // prefetch the next row's operands
+        static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD] + 8 * (i + 1)); });
+      float cn[D];
+      static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
+      row_allreduce<1>(m1, m2, sg);
+      const uint32_t sign31 = sg[0] & 0x80000000u;
+      if constexpr (VARIANT == CC_ALG_MS) {
+        const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
+        static_for<D>([&](auto DD) {
+          constexpr int d = DD;
+          const uint32_t t = f2u(__builtin_amdgcn_fmed3f(__builtin_fabsf(R[i][d]), u2f(m1[0]), u2f(m2[0])));
+          R[i][d] = u2f(xad(t, Y, f2u(R[i][d]) & 0x80000000u));
+        });
+      } else {
+        const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[0]), p.alpha_f, p.beta_d));
+        const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[0]), p.alpha_f, p.beta_d));
+        static_for<D>([&](auto DD) {
+          constexpr int d = DD;
+          const uint32_t mag = (__builtin_fabsf(R[i][d]) == u2f(m1[0])) ? H2 : H1;
+          R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
+        });
+      }
+      static_for<D>([&](auto DD) {
+        *reinterpret_cast<float *>(cn_lane + aCY[DD] + 8 * i) = cn[DD] + R[i][DD];  // ascending rows
+      });
+    });
+#else
     static_for<K / RB>([&](auto RBI) {
       constexpr int rb = RBI;
       uint32_t m1[RB], m2[RB], sg[RB];
@@ -239,6 +305,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         });
       });
     });
+
+#endif
 
     // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
     uint32_t pv = 0, any = 0;
@@ -341,12 +409,17 @@ bool minsum_diag_supported(const cc_code *code) {
   return code->tab.k == 24 && code->tab.row0_support.size() == 112 && code->tab.n == 255;
 }
 
+#ifndef CC_DIAG_PIPELINE
+#define CC_DIAG_PIPELINE 1
+#endif
 #ifndef CC_DIAG_RB
 #define CC_DIAG_RB 2
 #endif
 #define CC_STR2(x) #x
 #define CC_STR(x) CC_STR2(x)
-const char *minsum_diag_name(const cc_code *) { return "minsum_diag_kernel<K=24,D=7,RB=" CC_STR(CC_DIAG_RB) ">"; }
+const char *minsum_diag_name(const cc_code *) {
+  return CC_DIAG_PIPELINE ? "minsum_diag_kernel<K=24,D=7,row-pipelined>" : "minsum_diag_kernel<K=24,D=7,RB=" CC_STR(CC_DIAG_RB) ">";
+}
 
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
