@@ -389,6 +389,32 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D) {
       left.erase(left.begin() + static_cast<long>(best));
     }
   }
+  // local search: swap elements between groups while the total bank multiplicity (sum over slots of the
+  // largest number of lanes on one residue class -- the LDS passes a slot instruction needs) decreases
+  auto group_cost = [&](const std::vector<unsigned> &g) {
+    int cnt[16] = {0}, mx = 0, sq = 0;
+    for (unsigned s : g) ++cnt[s % W];
+    for (int c : cnt) {
+      mx = c > mx ? c : mx;
+      sq += c * c;
+    }
+    return mx * 1000 + sq;  // primary: max multiplicity, secondary: fewer doubled banks
+  };
+  bool improved = true;
+  while (improved) {
+    improved = false;
+    for (int a = 0; a < D && !improved; ++a)
+      for (int b = a + 1; b < D && !improved; ++b)
+        for (int x = 0; x < W && !improved; ++x)
+          for (int y = 0; y < W && !improved; ++y) {
+            const int before = group_cost(grp[a]) + group_cost(grp[b]);
+            std::swap(grp[a][x], grp[b][y]);
+            if (group_cost(grp[a]) + group_cost(grp[b]) < before)
+              improved = true;
+            else
+              std::swap(grp[a][x], grp[b][y]);
+          }
+  }
   std::vector<uint16_t> out(static_cast<size_t>(D) * W, 0);
   for (int g = 0; g < D; ++g)
     for (int l = 0; l < W; ++l) out[g * W + l] = static_cast<uint16_t>(grp[g][l]);
