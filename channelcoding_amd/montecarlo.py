@@ -159,3 +159,63 @@ class awgn_simulation:
         if log:
             log.close()
         return results
+
+
+class bitflip_simulation:
+    """bitflip_simulation(decoder, errors) -- simulation.h:85-92, simulation.c++:152-213.
+
+    Exhaustive word-error rate by number of flipped bits: for every weight w <= errors and every one of the
+    C(n, w) flip patterns the all-zero word is sent as +1 / -1 (x = -2*bit + 1, :190-191), decoded, and
+    counted as a word error when the result is non-zero or the decoder fails (:193-199).  The reference
+    walks the patterns with std::next_permutation one frame at a time; here all patterns of a weight are
+    decoded as one batch on the GPU.
+    """
+
+    def __init__(self, code, errors=0, log_dir=None, batch=1 << 18):
+        self.code, self.errors, self.log_dir, self.batch = code, int(errors), log_dir, int(batch)
+
+    def patterns(self, w):
+        """All C(n, w) flip patterns as rows of positions, in chunks of at most `batch` rows."""
+        import itertools
+        n = self.code.n
+        if w == 0:
+            yield np.zeros((1, 0), np.int64)
+            return
+        it = itertools.combinations(range(n), w)
+        while True:
+            chunk = np.fromiter(itertools.chain.from_iterable(itertools.islice(it, self.batch)), np.int64)
+            if chunk.size == 0:
+                return
+            yield chunk.reshape(-1, w)
+
+    def run_weight(self, w):
+        import torch
+        n = self.code.n
+        patterns = word_errors = 0
+        for pos in self.patterns(w):
+            x = torch.ones((pos.shape[0], n), dtype=torch.float32, device="cuda")
+            if w:
+                x.scatter_(1, torch.from_numpy(pos).cuda(), -1.0)
+            res = self.code.correct_batch(x)
+            bad = (res["status"] != 0) | (res["out"] != 0).any(dim=1)
+            patterns += pos.shape[0]
+            word_errors += int(bad.sum())
+        return patterns, word_errors
+
+    def __call__(self):
+        log = None
+        if self.log_dir is not None:
+            path = os.path.join(self.log_dir, self.code.to_string() + ".log")
+            if os.path.exists(path):
+                raise RuntimeError("File %s already exists." % path)
+            log = open(path, "w")
+            log.write("%7s %21s\n" % ("errors", "wer"))
+        out = []
+        for w in range(self.errors + 1):
+            patterns, word_errors = self.run_weight(w)
+            out.append(dict(errors=w, patterns=patterns, word_errors=word_errors, wer=word_errors / patterns))
+            if log:
+                log.write("%7s %s\n" % ("%.6g" % w, "%16.15e" % (word_errors / patterns)))
+        if log:
+            log.close()
+        return out
