@@ -18,9 +18,10 @@
 //     "syndromes of the error pattern equal the received syndromes" (linearity);
 //   * the reference's BM reads lambda out of bounds when deg(lambda) < l; lanes
 //     beyond the degree hold zero here, which is the textbook algorithm.
-//   * PGZ and Euklid tags decode to the same word as BM whenever at most t errors (+ erasures
-//     within capability) occurred; they are run as "BM + degree bound" (bounded-distance
-//     decoding), see DESIGN.md for the reference defects this sidesteps (Q9).
+//   * the Euklid tag runs Sugiyama's algorithm itself (hard_decision.h:157-196), including erasures;
+//   * the PGZ tag decodes to the same word as BM whenever at most t errors occurred; it is run as
+//     "BM + degree bound" (bounded-distance decoding), see DESIGN.md for the reference defect this
+//     sidesteps (Q9).
 //
 // Lane roles: in the syndrome / root-search / verify phases lane l owns the positions
 // p = l + 64c (c < 4); in the Berlekamp-Massey phase lane j owns coefficient j of lambda and b.
@@ -127,16 +128,58 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
     int status = CC_FRAME_OK;
     int nerr = 0;
     uint32_t corr[4] = {0, 0, 0, 0};
-    if (any_syndrome != 0) {  // wave-uniform
+    if (any_syndrome != 0 && nerase > static_cast<uint32_t>(t2)) {
+      status = CC_FRAME_ERASURES;  // more erasures than 2t cannot be located (bch.h:105-107)
+    } else if (any_syndrome != 0) {  // wave-uniform
+      uint32_t lam;
+      const int rho = static_cast<int>(nerase);
+      if (alg == CC_ALG_EUKLID) {
+        // ---- Euklid / Sugiyama with erasures, hard_decision.h:157-196 (lane j <-> coefficient j) ----
+        // r_prev = S(x) u(x), r_cur = x^2t, w_prev = u, w_cur = 0; divide until deg r_cur < (2t + rho) / 2;
+        // lambda = w_cur / w_cur(0).  One long-division step per loop trip, at most 2t + rho trips.
+        uint32_t u = (lane == 0) ? 1u : 0u;
+        for (uint32_t e = 0; e < nerase; ++e) u ^= gmul(ex[er[ebase + e] % nn], shift_up(u));  // :171-172
+        uint32_t rp = 0;  // S(x) * u(x): coefficient j = sum_m S_{j-m} u_m
+        for (int m = 0; m <= rho; ++m) {
+          const uint32_t um = __builtin_amdgcn_readlane(u, m);
+          const uint32_t sj = (lane >= m && lane - m < t2) ? W.S[lane - m] : 0u;
+          rp ^= gmul(um, sj);
+        }
+        uint32_t rc = (lane == t2) ? 1u : 0u, wp = u, wc = 0u;
+        const int max_deg = (t2 + rho) / 2;
+        auto degree_of = [&](uint32_t v) { return 63 - __builtin_clzll(__ballot(v != 0) | 1ull) - ((__ballot(v != 0) == 0) ? 1 : 0); };
+        int guard = 0;
+        while (degree_of(rc) >= max_deg && guard++ < 130) {
+          // one Euclid step: (q, next) = divmod(rp, rc); w_next = wp + q * wc
+          const int dr = degree_of(rc);
+          const uint32_t lead = __builtin_amdgcn_readlane(rc, dr);
+          uint32_t rem = rp, wn = wp;
+          for (int pos = degree_of(rem); pos >= dr; --pos) {
+            const uint32_t top = __builtin_amdgcn_readlane(rem, pos);
+            if (top == 0) continue;
+            const uint32_t coef = ex[lg[top] + nn - lg[lead]];
+            const int sh = pos - dr;
+            const uint32_t rc_sh = __shfl(rc, lane - sh, 64), wc_sh = __shfl(wc, lane - sh, 64);
+            rem ^= (lane >= sh) ? gmul(coef, rc_sh) : 0u;
+            wn ^= (lane >= sh) ? gmul(coef, wc_sh) : 0u;
+          }
+          rp = rc;
+          rc = rem;
+          wp = wc;
+          wc = wn;
+        }
+        const uint32_t w0 = __builtin_amdgcn_readlane(wc, 0);
+        if (w0 == 0) status = CC_FRAME_LOCATOR;  // "Cannot invert last element", :191-192
+        lam = (w0 && wc) ? ex[lg[wc] + nn - lg[w0]] : 0u;
+      } else {
       // ---- Berlekamp-Massey, hard_decision.h:116-155 (lane j <-> coefficient j) ----
-      uint32_t lam = (lane == 0) ? 1u : 0u;
+      lam = (lane == 0) ? 1u : 0u;
       for (uint32_t e = 0; e < nerase; ++e) {  // lambda *= (1 + alpha^erasure x), :128-131
         const uint32_t X = ex[er[ebase + e] % nn];
         lam ^= gmul(X, shift_up(lam));
       }
       uint32_t bpoly = lam;
       int l = static_cast<int>(nerase);
-      const int rho = static_cast<int>(nerase);
       for (int i = rho; i < t2; ++i) {
         bpoly = shift_up(bpoly);  // b = b * x
         const bool in_sum = lane >= 1 && lane <= l && lane <= i;
@@ -151,11 +194,12 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
           lam = tnew;
         }
       }
+      }
       const unsigned long long nz = __ballot(lam != 0);
       const int deg = 63 - __builtin_clzll(nz | 1ull);
       W.lam[lane] = static_cast<uint8_t>(lam);  // 64 coefficients
-      // bounded-distance mode for the PGZ / Euklid tags: locator degree within capability
-      if (alg != CC_ALG_BM && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;
+      // the PGZ tag runs as bounded-distance decoding: locator degree within capability
+      if (alg == CC_ALG_PGZ && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;
       if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
 
       // ---- root search: position p is in error iff lambda(alpha^-p) = 0 ----
@@ -247,7 +291,91 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
   }
 }
 
+// ---- primitive_bch::correct with PGZ and erasures, bch.h:97-149: decode twice with the erased positions
+//      forced to 0 and to 1, keep the result with fewer corrected errors (the first wins ties) ----
+__global__ void __launch_bounds__(256)
+force_erasures_kernel(const uint8_t *__restrict__ in, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
+                      uint8_t *__restrict__ in0, uint8_t *__restrict__ in1, int n, unsigned long long B) {
+  const unsigned long long total = B * static_cast<unsigned long long>(n);
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += stride) {
+    const unsigned long long f = idx / n;
+    const int p = static_cast<int>(idx - f * n);
+    bool erased = false;
+    for (uint32_t e = er_off[f]; e < er_off[f + 1]; ++e) erased |= (er[e] == p);
+    const uint8_t v = in[idx];
+    in0[idx] = erased ? 0 : v;
+    in1[idx] = erased ? 1 : v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+select_trial_kernel(const uint8_t *__restrict__ in, const uint32_t *__restrict__ er_off, uint8_t *__restrict__ out0,
+                    int32_t *__restrict__ nerr0, int32_t *__restrict__ st0, const uint8_t *__restrict__ out1,
+                    const int32_t *__restrict__ nerr1, const int32_t *__restrict__ st1, int n, int t2,
+                    unsigned long long B) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+    const uint32_t ne = er_off[f + 1] - er_off[f];
+    if (ne == 0) continue;  // trial 0 decoded the untouched word: the plain path (bch.h:100-101)
+    const int s0 = st0[f], s1 = st1[f], e0 = nerr0[f], e1 = nerr1[f];
+    int pick, status;
+    if (ne > static_cast<uint32_t>(t2)) {
+      pick = -1;
+      status = CC_FRAME_ERASURES;  // bch.h:105-107
+    } else if (s0 != CC_FRAME_OK && s1 != CC_FRAME_OK) {
+      pick = -1;
+      status = CC_FRAME_LOCATOR;  // "Erasure decoding failed."
+    } else {
+      pick = (s0 != CC_FRAME_OK || (s1 == CC_FRAME_OK && e1 < e0)) ? 1 : 0;
+      status = CC_FRAME_OK;
+    }
+    for (int p = lane; p < n; p += 64) {
+      const uint8_t v = pick < 0 ? in[f * n + p] : (pick == 1 ? out1[f * n + p] : out0[f * n + p]);
+      out0[f * n + p] = v;
+    }
+    if (lane == 0) {
+      if (nerr0) nerr0[f] = pick < 0 ? -1 : (pick == 1 ? e1 : e0);
+      if (st0) st0[f] = status;
+    }
+  }
+}
+
 }  // namespace
+
+int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                     const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                     hipStream_t stream);
+
+int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,
+                        uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n;
+  uint8_t *in0 = nullptr, *in1 = nullptr, *out1 = nullptr;
+  int32_t *aux = nullptr;  // nerr0, st0 (when the caller passed none), nerr1, st1
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&in0), 3 * B * n, stream));
+  in1 = in0 + B * n;
+  out1 = in1 + B * n;
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&aux), 4 * B * sizeof(int32_t), stream));
+  int32_t *nerr0 = d_nerr ? d_nerr : aux, *st0 = d_status ? d_status : aux + B, *nerr1 = aux + 2 * B, *st1 = aux + 3 * B;
+  const unsigned long long Bq = B;
+  const int grid = code->num_cus * 8;
+  hipLaunchKernelGGL(force_erasures_kernel, dim3(grid), dim3(256), 0, stream, d_in, d_er, d_er_off, in0, in1,
+                     static_cast<int>(n), Bq);
+  int rc = launch_algebraic(code, false, in0, nullptr, nullptr, d_out, nerr0, st0, B, stream);
+  if (rc == CC_OK) rc = launch_algebraic(code, false, in1, nullptr, nullptr, out1, nerr1, st1, B, stream);
+  if (rc == CC_OK) {
+    hipLaunchKernelGGL(select_trial_kernel, dim3(grid), dim3(256), 0, stream, d_in, d_er_off, d_out, nerr0, st0, out1,
+                       nerr1, st1, static_cast<int>(n), static_cast<int>(code->tab.roots.size()), Bq);
+    if (hipGetLastError() != hipSuccess) rc = CC_ERR_HIP;
+  }
+  (void)hipFreeAsync(in0, stream);
+  (void)hipFreeAsync(aux, stream);
+  return rc;
+}
 
 int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,

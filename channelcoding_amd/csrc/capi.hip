@@ -365,17 +365,10 @@ static int hard_supported(const cc_code *code, bool erasures) {
     set_last_error("RS error values on the device assume roots alpha^1..alpha^2t (mu = step = 1), as rs.h:55-69 does");
     return CC_ERR_UNSUPPORTED;
   }
-  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
-    // RS: the reference throws std::runtime_error (hard_decision.h:66-68); BCH: two-trial trick bch.h:97-149
-    set_last_error("PGZ with erasures is not available on the device path");
-    return CC_ERR_UNSUPPORTED;
-  }
-  if (erasures && code->desc.algorithm == CC_ALG_EUKLID) {
-    // Without erasures Euklid == bounded-distance decoding == BM with a degree bound (bit-exact, tested).
-    // With erasures the reference's stopping rule deg r < (2t+rho)/2 (hard_decision.h:181-186) selects a
-    // different locator than BM once the error count exceeds the capability, so the device path would not be
-    // bit-exact there; use berlekamp_massey_tag for erasure decoding.
-    set_last_error("Euklid with erasures is not available on the device path; use the BM tag");
+  if (erasures && code->desc.algorithm == CC_ALG_PGZ && code->tab.family == CC_FAMILY_RS) {
+    // std::runtime_error "The PGZ-Algorithm does not support erasure decoding" (hard_decision.h:66-68);
+    // for BCH the two-trial rule of bch.h:97-149 applies (launch_pgz_erasures)
+    set_last_error("The PGZ-Algorithm does not support erasure decoding");
     return CC_ERR_UNSUPPORTED;
   }
   return CC_OK;
@@ -389,6 +382,9 @@ int cc_correct_hard_batch_dev(const cc_code *code, const uint8_t *d_in, const ui
   const int rc = hard_supported(code, d_erasures != nullptr);
   if (rc != CC_OK) return rc;
   DeviceGuard guard(code->device);
+  if (d_erasures && code->desc.algorithm == CC_ALG_PGZ)
+    return launch_pgz_erasures(code, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
+                               static_cast<hipStream_t>(stream));
   return launch_algebraic(code, false, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
                           static_cast<hipStream_t>(stream));
 }
@@ -437,7 +433,9 @@ static int hard_host(const cc_code *code, bool float_in, const void *in, const u
     if (ne) CC_HIP_TRY(hipMemcpy(d_er.p, erasures, ne * sizeof(uint16_t), hipMemcpyHostToDevice));
     CC_HIP_TRY(hipMemcpy(d_off.p, erasure_offsets, (B + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  const int lrc = launch_algebraic(code, float_in, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr);
+  const int lrc = (erasures && code->desc.algorithm == CC_ALG_PGZ && !float_in)
+                      ? launch_pgz_erasures(code, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr)
+                      : launch_algebraic(code, float_in, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr);
   if (lrc != CC_OK) return lrc;
   CC_HIP_TRY(hipDeviceSynchronize());
   CC_HIP_TRY(hipMemcpy(out, d_out.p, B * n, hipMemcpyDeviceToHost));

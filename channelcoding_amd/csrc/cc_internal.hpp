@@ -100,6 +100,8 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
 int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
                      hipStream_t stream);
+int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,
+                        uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
 // encode.hip
 std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t);
 int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);

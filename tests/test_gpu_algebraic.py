@@ -122,7 +122,7 @@ def test_hard_from_soft_values(cid):
 
 
 @pytest.mark.parametrize("cid", [8, 9, 10, 5])
-def test_erasures_bm(cid):
+def test_erasures_bm_euklid(cid):
     """hard_decision.h:128-131,:171-172: erasure locators pre-loaded into lambda; per-frame CSR lists."""
     o = Oracle(*REF_CODES[cid])
     rng = np.random.default_rng(6200 + cid)
@@ -141,16 +141,38 @@ def test_erasures_bm(cid):
         for p in rng.choice(free, nerr, replace=False):
             rx[f, p] ^= 1 if o.family == BCH else int(rng.integers(1, hi))
         per.append(er)
-    res = make_code(cid, BM).correct_batch(rx, erasures=per)
+    for alg in (BM, EUKLID):
+        res = make_code(cid, alg).correct_batch(rx, erasures=per)
+        for f in range(frames):
+            out, nerr, st, ub = o.correct_hard(alg, rx[f], per[f])
+            assert (res["status"][f] == 0) == (st[0] == 0), (alg, f, per[f])
+            if alg == BM:
+                assert res["status"][f] == st[0]
+            if st[0] == 0:
+                assert np.array_equal(res["out"][f], out[0]) and res["nerr"][f] == nerr[0]
+
+
+def test_pgz_erasure_two_trial_rule_bch():
+    """bch.h:97-149: PGZ + erasures decodes twice (erasures := 0, := 1) and keeps the result with fewer errors."""
+    o = Oracle(BCH, 6, 3)
+    rng = np.random.default_rng(77)
+    frames = 300
+    cw = o.encode(rng.integers(0, 2, (frames, o.l)).astype(np.uint8))
+    rx = cw.copy()
+    per = []
     for f in range(frames):
-        out, nerr, st, ub = o.correct_hard(BM, rx[f], per[f])
-        assert res["status"][f] == st[0], (f, per[f])
+        er = sorted(rng.choice(o.n, int(rng.integers(0, 8)), replace=False).tolist())  # up to 7 > 2t = 6
+        for p in rng.choice(o.n, int(rng.integers(0, 4)), replace=False):
+            rx[f, p] ^= 1
+        per.append(er)
+    res = make_code(5, PGZ).correct_batch(rx, erasures=per)
+    for f in range(frames):
+        out, nerr, st, ub = o.correct_hard(PGZ, rx[f], per[f])
+        assert res["status"][f] == st[0], (f, per[f], res["status"][f], st[0])
         if st[0] == 0:
             assert np.array_equal(res["out"][f], out[0]) and res["nerr"][f] == nerr[0]
-    # Euklid + erasures: explicit refusal instead of a result that is not bit-exact beyond capability
-    with pytest.raises(cc.CcError) as e:
-        make_code(cid, EUKLID).correct_batch(rx, erasures=per)
-    assert e.value.status == capi.ERR_UNSUPPORTED
+        else:
+            assert np.array_equal(res["out"][f], rx[f]) and res["nerr"][f] == -1
 
 
 def test_api_errors_and_device_pointers():
