@@ -8,7 +8,7 @@ reference's classes plus the torch.distributed Monte-Carlo harness.
 """
 from . import _capi as capi
 from ._capi import CcError
-from .codes import (berlekamp_massey_tag, cyclic, decoding_failure, dmin, errors, euklid_tag, min_sum_tag,
+from .codes import (berlekamp_massey_tag, cyclic, decoding_failure, dmin, errors, euklid_tag, min_sum, min_sum_decoder, min_sum_tag,
                     normalized_2d_min_sum_tag, normalized_min_sum_tag, offset_min_sum_tag,
                     peterson_gorenstein_zierler_tag, primitive_bch, rs, self_correcting_1_min_sum_tag,
                     self_correcting_2_min_sum_tag)
@@ -17,5 +17,5 @@ __all__ = [
     "capi", "CcError", "cyclic", "primitive_bch", "rs", "errors", "dmin", "decoding_failure",
     "peterson_gorenstein_zierler_tag", "berlekamp_massey_tag", "euklid_tag", "min_sum_tag",
     "normalized_min_sum_tag", "offset_min_sum_tag", "self_correcting_1_min_sum_tag",
-    "self_correcting_2_min_sum_tag", "normalized_2d_min_sum_tag",
+    "self_correcting_2_min_sum_tag", "normalized_2d_min_sum_tag", "min_sum", "min_sum_decoder",
 ]

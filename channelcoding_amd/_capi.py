@@ -57,6 +57,9 @@ _SIGNATURES = {
     "cc_to_string": (C.c_int, [_VP, C.c_char_p, C.c_size_t]),
     "cc_get_poly": (C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
     "cc_get_H": (C.c_int, [_VP, _VP]),
+    "cc_get_H_alt": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint32)]),
+    "cc_code_create_with_H": (C.c_int, [C.POINTER(Desc), _VP, C.c_uint32, C.POINTER(_VP)]),
+    "cc_minsum_create": (C.c_int, [C.POINTER(Desc), _VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "cc_encode_batch": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "cc_encode_batch_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_correct_hard_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),

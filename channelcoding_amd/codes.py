@@ -160,7 +160,7 @@ class cyclic:
     family = None
 
     def __init__(self, q, capability, algorithm=None, coding="division", mu=1, step=1,
-                 stop_rule=capi.STOP_PARITY, device=None):
+                 stop_rule=capi.STOP_PARITY, device=None, H=None):
         if isinstance(capability, int):
             capability = errors(capability)
         algorithm = algorithm if algorithm is not None else peterson_gorenstein_zierler_tag()
@@ -182,7 +182,14 @@ class cyclic:
         d.device = capi.DEVICE_CURRENT if device is None else int(device)
         self._desc = d
         h = C.c_void_p()
-        capi.check(lib.cc_code_create(C.byref(d), C.byref(h)), "cc_code_create")
+        if H is None:
+            capi.check(lib.cc_code_create(C.byref(d), C.byref(h)), "cc_code_create")
+        else:  # min_sum<float, U>(matrix, y, tag) on a caller-supplied parity-check matrix, e.g. H_alt()
+            Hm = np.ascontiguousarray(H, np.uint8)
+            if Hm.ndim != 2 or Hm.shape[1] != (1 << int(q)) - 1:
+                raise ValueError("H must be a (rows, n) matrix")
+            capi.check(lib.cc_code_create_with_H(C.byref(d), _ptr(Hm), Hm.shape[0], C.byref(h)),
+                       "cc_code_create_with_H")
         self._h = h
         self.q = int(q)
         self.n, self.k, self.l = lib.cc_n(h), lib.cc_k(h), lib.cc_l(h)
@@ -225,6 +232,22 @@ class cyclic:
         H = np.zeros((self.k, self.n), np.uint8)
         capi.check(capi.lib().cc_get_H(self._h, _ptr(H)), "cc_get_H")
         return H
+
+    def kernel_info(self):
+        """Which device kernel cc_correct_*_batch dispatches to for this handle (diagnostics, bench.py)."""
+        name = C.create_string_buffer(160)
+        fpw, thr, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        capi.check(capi.lib().cc_kernel_info(self._h, name, 160, C.byref(fpw), C.byref(thr), C.byref(lds)),
+                   "cc_kernel_info")
+        return {"kernel": name.value.decode(), "frames_per_workgroup": fpw.value, "threads": thr.value,
+                "lds_bytes": lds.value}
+
+    def H_alt(self):
+        """cyclic::H_alt<uint8_t>() (cyclic.h:361-385), t*q rows."""
+        H = np.zeros((self.t * self.q, self.n), np.uint8)
+        rows = C.c_uint32()
+        capi.check(capi.lib().cc_get_H_alt(self._h, _ptr(H), C.byref(rows)), "cc_get_H_alt")
+        return H[: rows.value]
 
     def sigma(self, ebno_db):
         return capi.lib().cc_sigma(self._h, float(ebno_db))
@@ -398,3 +421,49 @@ class rs(cyclic):
 
     def __init__(self, q, capability, algorithm=None, coding="division", mu=1, step=1, **kw):
         super().__init__(q, capability, algorithm, coding, mu, step, **kw)
+
+
+class min_sum_decoder(cyclic):
+    """The free functions min_sum<R, U>(H, y, tag) of soft_decision.h:220-295 bound to one parity-check matrix
+    (any rows x cols 0/1 matrix, cols <= 256; cc_minsum_create).  correct_batch(), correct(), H(), to_string()
+    and kernel_info() work; there is no code to encode with."""
+
+    def __init__(self, H, algorithm=None, stop_rule=capi.STOP_PARITY, device=None):
+        algorithm = algorithm if algorithm is not None else min_sum_tag()
+        if isinstance(algorithm, type):
+            algorithm = algorithm()
+        Hm = np.ascontiguousarray(H, np.uint8)
+        if Hm.ndim != 2:
+            raise ValueError("H must be a (rows, cols) matrix")
+        self.algorithm = algorithm
+        self.capability = None
+        lib = capi.lib()
+        d = capi.Desc()
+        lib.cc_desc_init(C.byref(d))
+        d.algorithm = algorithm.alg
+        d.iterations = algorithm.iterations
+        d.alpha, d.beta = float(algorithm.alpha), float(algorithm.beta)
+        d.stop_rule = int(stop_rule)
+        d.device = capi.DEVICE_CURRENT if device is None else int(device)
+        self._desc = d
+        h = C.c_void_p()
+        capi.check(lib.cc_minsum_create(C.byref(d), _ptr(Hm), Hm.shape[0], Hm.shape[1], C.byref(h)),
+                   "cc_minsum_create")
+        self._h = h
+        self.q = 0
+        self.n, self.k, self.l = lib.cc_n(h), lib.cc_k(h), lib.cc_l(h)
+        self.t, self.dmin, self.rate = 0, 0, lib.cc_rate(h)
+
+
+def min_sum(H, y, tag=None, stop_rule=capi.STOP_PARITY):
+    """min_sum<float, uint8_t>(H, y, tag): returns (b, L, iteration) like the reference's tuple and raises
+    decoding_failure when no iteration satisfies the stop rule (soft_decision.h:199-201).  One frame per call;
+    build a min_sum_decoder and use correct_batch for throughput."""
+    dec = min_sum_decoder(H, tag, stop_rule)
+    y = np.asarray(y, np.float32)
+    if y.ndim != 1 or y.shape[0] != dec.n:
+        raise CcError(capi.ERR_LENGTH, "min_sum")
+    res = dec.correct_batch(y[None, :], want_L=True)
+    if int(res["status"][0]) != capi.FRAME_OK:
+        raise decoding_failure(cyclic._MESSAGES[capi.FRAME_NOT_CONVERGED])
+    return res["out"][0], res["L"][0], int(res["iters"][0])

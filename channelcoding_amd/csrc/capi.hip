@@ -107,15 +107,17 @@ void cc_desc_init(cc_desc *d) {
   d->device = -1;
 }
 
-int cc_code_create(const cc_desc *desc, cc_code **out) {
+static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_t custom_rows, uint32_t custom_cols,
+                            cc_code **out) {
   if (!desc || !out || desc->struct_size != sizeof(cc_desc)) return CC_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (!is_soft(desc->algorithm) && !is_hard(desc->algorithm)) return CC_ERR_INVALID_ARGUMENT;
-  if (desc->family != CC_FAMILY_BCH && desc->family != CC_FAMILY_RS) return CC_ERR_INVALID_ARGUMENT;
+  const bool matrix_only = custom_cols != 0;  // cc_minsum_create: the free min_sum(H, y, tag), no code behind it
+  if (!matrix_only && desc->family != CC_FAMILY_BCH && desc->family != CC_FAMILY_RS) return CC_ERR_INVALID_ARGUMENT;
   if (desc->stop_rule < CC_STOP_AS_SHIPPED || desc->stop_rule > CC_STOP_PARITY) return CC_ERR_INVALID_ARGUMENT;
   if (desc->coding != CC_CODING_DIVISION && desc->coding != CC_CODING_MULTIPLICATION) return CC_ERR_INVALID_ARGUMENT;
-  if (desc->q < 2 || desc->q > 8) return CC_ERR_INVALID_ARGUMENT;
-  if (desc->n != 0 && desc->n != (1u << desc->q) - 1) {
+  if (!matrix_only && (desc->q < 2 || desc->q > 8)) return CC_ERR_INVALID_ARGUMENT;
+  if (!matrix_only && desc->n != 0 && desc->n != (1u << desc->q) - 1) {
     set_last_error("shortened codes (N != 2^q-1) are not supported");
     return CC_ERR_UNSUPPORTED;
   }
@@ -134,9 +136,17 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
   if (!code) return CC_ERR_OUT_OF_MEMORY;
   code->desc = *desc;
   code->device = dev;
+  code->matrix_only = matrix_only;
   try {
-    code->field.reset(new Field(desc->q));
-    code->tab = build_code(*code->field, desc->family, desc->t, desc->mu, desc->step);
+    if (matrix_only) {
+      code->tab.family = CC_FAMILY_BCH;
+      code->tab.n = custom_cols;
+      code->tab.k = custom_rows;
+      code->tab.l = custom_cols > custom_rows ? custom_cols - custom_rows : 0;
+    } else {
+      code->field.reset(new Field(desc->q));
+      code->tab = build_code(*code->field, desc->family, desc->t, desc->mu, desc->step);
+    }
   } catch (const std::invalid_argument &e) {
     set_last_error(e.what());
     return CC_ERR_INVALID_ARGUMENT;
@@ -145,6 +155,17 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
     return CC_ERR_INVALID_ARGUMENT;
   }
   code->soft = is_soft(desc->algorithm);
+  code->ms_rows = code->tab.k;
+  if (customH) {
+    if (!code->soft || custom_rows == 0) {
+      set_last_error("a custom parity-check matrix needs a min-sum algorithm and at least one row");
+      return CC_ERR_INVALID_ARGUMENT;
+    }
+    code->custom_H.assign(customH, customH + static_cast<size_t>(custom_rows) * code->tab.n);
+    code->ms_rows = custom_rows;
+    for (uint8_t v : code->custom_H)
+      if (v > 1) code->tab.binary_h = false;
+  }
   {
     const char *fg = std::getenv("CC_AMD_FORCE_GENERIC");
     code->force_generic = fg && fg[0] == '1';
@@ -152,22 +173,17 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
   const CodeTables &t = code->tab;
   {
     char buf[96];
-    std::snprintf(buf, sizeof buf, "(%u, %u, %u)-%s", t.n, t.l, t.dmin, alg_name(desc->algorithm));
+    if (matrix_only)
+      std::snprintf(buf, sizeof buf, "%ux%u-%s", t.k, t.n, alg_name(desc->algorithm));
+    else
+      std::snprintf(buf, sizeof buf, "(%u, %u, %u)-%s", t.n, t.l, t.dmin, alg_name(desc->algorithm));
     code->name = buf;
   }
   if (code->soft && !t.binary_h) {
     set_last_error("min-sum over a non-binary parity-check matrix (RS) is not supported");
     return CC_ERR_UNSUPPORTED;
   }
-  if (dev == CC_DEVICE_NONE) {
-    *out = code.release();
-    return CC_OK;
-  }
-  DeviceGuard guard(dev);
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) code->num_cus = prop.multiProcessorCount;
-
-  if (code->soft) {
+  if (code->soft) {  // lanes per frame (W) and columns per lane (C) of the min-sum kernels
     MinSumGeometry &g = code->geo;
     if (t.n <= 16) {
       g.W = 16;
@@ -186,20 +202,35 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
       g.C = 4;
     }
     g.frames_per_wave = 64 / g.W;
-    g.KW = static_cast<int>((t.k + 31) / 32);
+    g.KW = static_cast<int>((code->ms_rows + 31) / 32);
+  }
+  if (dev == CC_DEVICE_NONE) {
+    *out = code.release();
+    return CC_OK;
+  }
+  DeviceGuard guard(dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) code->num_cus = prop.multiProcessorCount;
+
+  if (code->soft) {
+    MinSumGeometry &g = code->geo;
     std::vector<uint32_t> cm(static_cast<size_t>(g.KW) * g.C * 64, 0u);
     for (int lane = 0; lane < 64; ++lane) {
       const int li = lane % g.W;
       for (int c = 0; c < g.C; ++c) {
         const unsigned j = static_cast<unsigned>(li + g.W * c);
         if (j >= t.n) continue;
-        for (unsigned i = 0; i < t.k && i <= j; ++i)  // H[i][j] = row0[j - i], cyclic.h:346-359
-          if (t.row0[j - i]) cm[(static_cast<size_t>(i >> 5) * g.C + c) * 64 + lane] |= 1u << (i & 31);
+        for (unsigned i = 0; i < code->ms_rows; ++i) {
+          const bool edge = code->custom_H.empty() ? (i <= j && t.row0[j - i] != 0)  // H[i][j] = row0[j - i], cyclic.h:346-359
+                                                   : (code->custom_H[static_cast<size_t>(i) * t.n + j] != 0);
+          if (edge) cm[(static_cast<size_t>(i >> 5) * g.C + c) * 64 + lane] |= 1u << (i & 31);
+        }
       }
     }
     CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
     CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (t.n == 255 && t.k <= 32 && t.row0_support.size() % 16 == 0 && t.row0_support.size() / 16 == 7) {
+    if (code->custom_H.empty() && t.n == 255 && t.k <= 32 && t.row0_support.size() % 16 == 0 &&
+        t.row0_support.size() / 16 == 7) {
       const std::vector<uint16_t> dg = build_diag_table(t, 7);
       std::vector<uint32_t> cb(256, 0u);
       for (unsigned j = 0; j < t.n; ++j)
@@ -210,7 +241,7 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
       CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colbits), cb.size() * sizeof(uint32_t)));
       CC_HIP_TRY(hipMemcpy(code->d_colbits, cb.data(), cb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (g.W == 64) {
+    if (g.W == 64 && code->custom_H.empty()) {
       std::vector<uint64_t> em(static_cast<size_t>(t.k) * g.C, 0ull);
       for (unsigned i = 0; i < t.k; ++i)
         for (int c = 0; c < g.C; ++c)
@@ -221,6 +252,10 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
       CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_emask), em.size() * sizeof(uint64_t)));
       CC_HIP_TRY(hipMemcpy(code->d_emask, em.data(), em.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
+  }
+  if (matrix_only) {
+    *out = code.release();
+    return CC_OK;
   }
   AlgebraicTables &a = code->h_alg;
   std::memset(&a, 0, sizeof a);
@@ -244,6 +279,44 @@ int cc_code_create(const cc_desc *desc, cc_code **out) {
   }
 
   *out = code.release();
+  return CC_OK;
+}
+
+int cc_code_create(const cc_desc *desc, cc_code **out) { return code_create_impl(desc, nullptr, 0, 0, out); }
+
+int cc_code_create_with_H(const cc_desc *desc, const uint8_t *H, uint32_t rows, cc_code **out) {
+  if (!H) return CC_ERR_INVALID_ARGUMENT;
+  return code_create_impl(desc, H, rows, 0, out);
+}
+
+int cc_minsum_create(const cc_desc *desc, const uint8_t *H, uint32_t rows, uint32_t cols, cc_code **out) {
+  if (!H || rows == 0 || cols == 0) return CC_ERR_INVALID_ARGUMENT;
+  if (cols > 256) {
+    set_last_error("min-sum kernels hold one frame per wavefront: at most 256 columns");
+    return CC_ERR_UNSUPPORTED;
+  }
+  return code_create_impl(desc, H, rows, cols, out);
+}
+
+static int needs_code(const cc_code *c) {
+  if (c->matrix_only) {
+    set_last_error("handle was made by cc_minsum_create: it has a parity-check matrix but no code behind it");
+    return CC_ERR_INVALID_ARGUMENT;
+  }
+  return CC_OK;
+}
+
+int cc_get_H_alt(const cc_code *c, uint8_t *H, uint32_t *rows) {
+  if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
+  if (needs_code(c) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  const unsigned n = c->tab.n, q = c->tab.q, t = c->tab.t;
+  for (unsigned r = 0; r < t; ++r)
+    for (unsigned bit = 0; bit < q; ++bit)
+      for (unsigned col = 0; col < n; ++col) {
+        const uint8_t v = c->field->alpha_pow(col * (2 * r + 1));  // from_power: exponent mod 2^q (sic)
+        H[(static_cast<size_t>(r) * q + bit) * n + col] = (v >> bit) & 1u;
+      }
+  if (rows) *rows = t * q;
   return CC_OK;
 }
 
@@ -286,6 +359,10 @@ int cc_get_poly(const cc_code *c, int which, uint8_t *out, size_t cap) {
 int cc_get_H(const cc_code *c, uint8_t *H) {
   if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
   const unsigned n = c->tab.n;
+  if (c->matrix_only) {
+    std::memcpy(H, c->custom_H.data(), c->custom_H.size());
+    return CC_OK;
+  }
   for (unsigned i = 0; i < c->tab.k; ++i)
     for (unsigned j = 0; j < n; ++j) H[i * n + j] = c->tab.row0[(j + n - i) % n];
   return CC_OK;
@@ -361,6 +438,10 @@ static int hard_supported(const cc_code *code, bool erasures) {
     return CC_ERR_INVALID_ARGUMENT;
   }
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  if (code->tab.roots.size() > 64) {  // one wavefront lane per syndrome / locator coefficient (algebraic.hip)
+    set_last_error("the algebraic kernel handles at most 64 syndromes (t <= 32)");
+    return CC_ERR_UNSUPPORTED;
+  }
   if (code->tab.family == CC_FAMILY_RS && (code->desc.mu != 1 || code->desc.step != 1)) {
     set_last_error("RS error values on the device assume roots alpha^1..alpha^2t (mu = step = 1), as rs.h:55-69 does");
     return CC_ERR_UNSUPPORTED;
@@ -458,6 +539,7 @@ int cc_correct_hard_f32_batch(const cc_code *code, const float *in, uint8_t *out
 
 int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, void *stream) {
   if (!code || (B && (!d_msg || !d_cw))) return CC_ERR_INVALID_ARGUMENT;
+  if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   DeviceGuard guard(code->device);
   return launch_encode(code, d_msg, d_cw, B, static_cast<hipStream_t>(stream));
@@ -465,6 +547,7 @@ int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw
 
 int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, void *stream) {
   if (!code || (B && (!d_cw || !d_msg))) return CC_ERR_INVALID_ARGUMENT;
+  if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   DeviceGuard guard(code->device);
   return launch_extract(code, d_cw, d_msg, B, static_cast<hipStream_t>(stream));
@@ -472,6 +555,7 @@ int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_ms
 
 static int byte_map_host(const cc_code *code, bool encode, const uint8_t *src, uint8_t *dst, size_t B) {
   if (!code || (B && (!src || !dst))) return CC_ERR_INVALID_ARGUMENT;
+  if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   if (B == 0) return CC_OK;
   const size_t n = code->tab.n, l = code->tab.l;
@@ -503,6 +587,7 @@ int cc_extract_batch(const cc_code *code, const uint8_t *cw, uint8_t *msg, size_
 /* ------------------------------ Monte-Carlo ------------------------------ */
 
 static int mc_supported(const cc_code *code) {
+  if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   if (code->tab.family != CC_FAMILY_BCH) {
     set_last_error("the BPSK/AWGN Monte-Carlo channel is defined for binary (BCH) codes");

@@ -31,6 +31,8 @@ struct MinSumParams {
   float beta_f;     // 2D-NMS vertical factor        (soft_decision.h:215-218: const R& beta)
   double beta_d;    // OMS offset, evaluated in double (soft_decision.h:245-251)
   const uint32_t *colmask;  // device
+  float *gstate;            // generic kernel, state too large for LDS: per-workgroup slabs in HBM (else nullptr)
+  unsigned long long gslab; // floats per workgroup slab
 };
 
 // device-resident tables of one code for the algebraic chain and the encoder
@@ -55,6 +57,9 @@ struct cc_code {
   std::unique_ptr<ccamd::Field> field;
   ccamd::CodeTables tab;
   bool soft = false;
+  std::vector<uint8_t> custom_H;  // rows x n, empty = the code's own H()
+  bool matrix_only = false;  // cc_minsum_create: no field / code tables
+  unsigned ms_rows = 0;           // check nodes of the min-sum graph (tab.k unless custom_H)
   ccamd::MinSumGeometry geo;
   uint32_t *d_colmask = nullptr;
   uint16_t *d_diag = nullptr;    // [D][16] diagonal (row-0 support) dealt to 16 lanes x D slots (minsum_diag)

@@ -63,8 +63,11 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
 // (and q for the self-correcting variants) in LDS, one wave per workgroup,
 // 64/W frames per wave.  Correct for every supported code; the specialised
 // register-resident kernels below take over for the benchmark geometries.
+// GSTATE: the k x n message state exceeds the 160 KiB of LDS (long low-rate
+// codes, large caller-supplied matrices) and lives in a per-workgroup HBM slab
+// instead -- same addressing (64 consecutive floats per access), L2-resident.
 // ---------------------------------------------------------------------------
-template <int C, int W, int VARIANT>
+template <int C, int W, int VARIANT, bool GSTATE>
 __global__ void __launch_bounds__(64)
 minsum_generic_kernel(MinSumParams p, const float *__restrict__ llr, const uint16_t *__restrict__ er,
                       const uint32_t *__restrict__ er_off, uint8_t *__restrict__ hard, float *__restrict__ Lout,
@@ -76,8 +79,8 @@ minsum_generic_kernel(MinSumParams p, const float *__restrict__ llr, const uint1
   const int li = lane & (W - 1);
   const int sub = lane / W;
   const int n = p.n, K = p.K;
-  float *R = lds;
-  float *Q = lds + static_cast<size_t>(K) * C * 64;
+  float *R = GSTATE ? p.gstate + static_cast<size_t>(blockIdx.x) * p.gslab : lds;
+  float *Q = R + static_cast<size_t>(K) * C * 64;
   const unsigned long long group_mask = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
   const int group_shift = sub * W;
 
@@ -222,17 +225,17 @@ minsum_generic_kernel(MinSumParams p, const float *__restrict__ llr, const uint1
   }
 }
 
-template <int C, int W>
+template <int C, int W, bool GSTATE>
 hipError_t launch_generic_variant(const MinSumParams &p, int grid, size_t lds, hipStream_t st, const float *llr,
                                   const uint16_t *er, const uint32_t *er_off, uint8_t *hard, float *L,
                                   uint16_t *iters, int32_t *status, unsigned long long B) {
 #define CC_LAUNCH(V)                                                                                              \
   if (lds > 48 * 1024) {                                                                                          \
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_generic_kernel<C, W, V>),          \
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_generic_kernel<C, W, V, GSTATE>),          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));       \
     if (ea != hipSuccess) return ea;                                                                              \
   }                                                                                                               \
-  hipLaunchKernelGGL((minsum_generic_kernel<C, W, V>), dim3(grid), dim3(64), lds, st, p, llr, er, er_off, hard, L, \
+  hipLaunchKernelGGL((minsum_generic_kernel<C, W, V, GSTATE>), dim3(grid), dim3(64), lds, st, p, llr, er, er_off, hard, L, \
                      iters, status, B);                                                                           \
   break
   switch (p.variant) {
@@ -250,7 +253,7 @@ hipError_t launch_generic_variant(const MinSumParams &p, int grid, size_t lds, h
 
 size_t generic_lds_bytes(const cc_code *code) {
   const bool needq = code->desc.algorithm == CC_ALG_SCMS1 || code->desc.algorithm == CC_ALG_SCMS2;
-  return static_cast<size_t>(code->tab.k) * code->geo.C * 64 * sizeof(float) * (needq ? 2 : 1);
+  return static_cast<size_t>(code->ms_rows) * code->geo.C * 64 * sizeof(float) * (needq ? 2 : 1);
 }
 
 }  // namespace
@@ -264,7 +267,7 @@ int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_
     lds = 4 * (4 * 272 * 12) + 1024;
     return CC_OK;
   }
-  if (minsum_reg_supported(code)) {
+  if (minsum_reg_supported(code) && !code->force_generic) {
     name = minsum_reg_name(code);
     frames_per_wg = 4;
     threads = 256;
@@ -275,6 +278,10 @@ int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_
   frames_per_wg = static_cast<uint32_t>(code->geo.frames_per_wave);
   threads = 64;
   lds = static_cast<uint32_t>(generic_lds_bytes(code));
+  if (lds > 160 * 1024) {
+    name += "[state in HBM]";
+    lds = 0;
+  }
   return CC_OK;
 }
 
@@ -283,7 +290,7 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   if (B == 0) return CC_OK;
   MinSumParams p;
   p.n = static_cast<int>(code->tab.n);
-  p.K = static_cast<int>(code->tab.k);
+  p.K = static_cast<int>(code->ms_rows);
   p.KW = code->geo.KW;
   p.variant = code->desc.algorithm;
   p.stop_rule = code->desc.stop_rule;
@@ -298,27 +305,40 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   if (minsum_reg_supported(code) && !code->force_generic)
     return launch_minsum_reg(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 
-  const size_t lds = generic_lds_bytes(code);
-  if (lds > 160 * 1024) {
-    set_last_error("min-sum state does not fit the 160 KiB LDS of one CU for this code");
-    return CC_ERR_UNSUPPORTED;
-  }
+  size_t lds = generic_lds_bytes(code);
+  const bool gstate = lds > 160 * 1024;
   const int fpw = code->geo.frames_per_wave;
   const unsigned long long groups = (B + fpw - 1) / fpw;
-  const unsigned long long waves_per_cu = lds ? (160 * 1024) / lds : 32;
-  unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * (waves_per_cu > 32 ? 32 : waves_per_cu);
+  unsigned long long waves_per_cu = gstate ? 16 : (lds ? (160 * 1024) / lds : 32);
+  if (waves_per_cu > 32) waves_per_cu = 32;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * waves_per_cu;
   const int grid = static_cast<int>(groups < max_grid ? groups : max_grid);
+  p.gstate = nullptr;
+  p.gslab = lds / sizeof(float);
+  if (gstate) {  // stream-ordered scratch: one slab per resident workgroup, freed behind the kernel
+    hipError_t ea = hipMallocAsync(reinterpret_cast<void **>(&p.gstate), lds * static_cast<size_t>(grid), stream);
+    if (ea != hipSuccess) return hip_fail(ea, "hipMallocAsync(min-sum state)");
+    lds = 0;
+  }
   hipError_t e = hipErrorInvalidValue;
   const unsigned long long Bq = B;
-#define CC_GEO(CC, WW)                                                                                        \
-  if (code->geo.C == CC && code->geo.W == WW)                                                                 \
-  e = launch_generic_variant<CC, WW>(p, grid, lds, stream, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq)
-  CC_GEO(1, 16);
-  CC_GEO(1, 32);
-  CC_GEO(1, 64);
-  CC_GEO(2, 64);
-  CC_GEO(4, 64);
+#define CC_GEO(CC, WW, GS)                                                                                       \
+  if (code->geo.C == CC && code->geo.W == WW && gstate == GS)                                                    \
+  e = launch_generic_variant<CC, WW, GS>(p, grid, lds, stream, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,      \
+                                         d_status, Bq)
+  CC_GEO(1, 16, false);
+  CC_GEO(1, 32, false);
+  CC_GEO(1, 64, false);
+  CC_GEO(2, 64, false);
+  CC_GEO(4, 64, false);
+  CC_GEO(1, 64, true);
+  CC_GEO(2, 64, true);
+  CC_GEO(4, 64, true);
 #undef CC_GEO
+  if (p.gstate) {
+    const hipError_t ef = hipFreeAsync(p.gstate, stream);
+    if (e == hipSuccess) e = ef;
+  }
   if (e != hipSuccess) return hip_fail(e, "minsum kernel launch");
   return CC_OK;
 }

@@ -36,7 +36,7 @@
 namespace ccamd {
 namespace {
 
-constexpr float kFltMax = 3.402823466e+38f;
+
 constexpr int kRegionCols = 272;  // 256 columns + 16 pad: odd frames start 16 banks later
 
 // compile-time loop: indices are literal constants from the start, so the register arrays below are

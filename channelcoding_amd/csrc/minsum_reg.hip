@@ -391,7 +391,7 @@ bool minsum_reg_supported(const cc_code *code) {
   if (alg == CC_ALG_OMS && !(code->desc.beta >= 0.0)) return false;  // h(0) must be 0 (see header)
   const float a = static_cast<float>(code->desc.alpha);
   if ((alg == CC_ALG_NMS || alg == CC_ALG_2DNMS) && !(a == a && a - a == 0.0f)) return false;  // finite alpha
-  if (code->geo.W != 64 || code->d_emask == nullptr) return false;
+  if (code->geo.W != 64 || code->d_emask == nullptr || !code->custom_H.empty()) return false;
   return rows_per_batch(static_cast<int>(code->tab.k), code->geo.C) != 0;
 }
 

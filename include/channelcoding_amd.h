@@ -133,6 +133,20 @@ int cc_get_poly(const cc_code *code, int which, uint8_t *out, size_t cap);
 /* cyclic::H<uint8_t>() cyclic.h:346-359, k*n bytes row-major */
 int cc_get_H(const cc_code *code, uint8_t *H);
 
+/* cyclic::H_alt<uint8_t>() cyclic.h:361-385: binary image of the t x n matrix alpha^(col*(2 row+1)), t*q rows
+ * (row r of the power matrix expands to q rows, least significant bit first).  Reproduces the reference's
+ * exponent reduction modulo 2^q (galois.h:182-184).  Writes t*q*n bytes; *rows = t*q. */
+int cc_get_H_alt(const cc_code *code, uint8_t *H, uint32_t *rows);
+/* Min-sum over a caller-supplied parity-check matrix (rows x n bytes, entries 0/1) instead of H(): what the
+ * reference spells min_sum<float, U>(code.H_alt<U>(), y, tag) (soft_decision.h:220-295).  The descriptor must
+ * name a min-sum algorithm; all other members of the new handle (encode, Monte-Carlo, ...) behave as usual. */
+int cc_code_create_with_H(const cc_desc *desc, const uint8_t *H, uint32_t rows, cc_code **out);
+/* The free functions min_sum<R, U>(H, y, tag) of soft_decision.h:220-295 on any rows x cols 0/1 matrix
+ * (cols <= 256), no code behind it: only algorithm, iterations, alpha, beta, stop_rule and device of the
+ * descriptor are read.  The handle serves cc_correct_soft_batch(_dev), cc_n (= cols), cc_k (= rows), cc_get_H,
+ * cc_to_string and cc_kernel_info; every entry point that needs a code returns CC_ERR_INVALID_ARGUMENT. */
+int cc_minsum_create(const cc_desc *desc, const uint8_t *H, uint32_t rows, uint32_t cols, cc_code **out);
+
 /* ---- encode: cyclic::encode cyclic.h:289-311 (+ free encode :29-40) ---- */
 int cc_encode_batch(const cc_code *code, const uint8_t *msg /* B*l */, uint8_t *cw /* B*n */, size_t B);
 int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, void *stream);

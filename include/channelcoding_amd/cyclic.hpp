@@ -23,6 +23,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -104,6 +105,10 @@ public:
   const std::vector<T> &at(size_t i) const { return data.at(i); }
   size_t rows() const { return data.size(); }
   size_t columns() const { return cols; }
+  void push_back(const std::vector<T> &row) {  // matrix.h push_back: rows must match the matrix width
+    if (row.size() != cols) throw std::runtime_error("Row size does not match matrix size");
+    data.push_back(row);
+  }
   typename std::vector<std::vector<T>>::const_iterator begin() const { return data.begin(); }
   typename std::vector<std::vector<T>>::const_iterator end() const { return data.end(); }
 };
@@ -293,6 +298,16 @@ public:
     return m;
   }
 
+  template <typename T> matrix<T> H_alt() const {  // cyclic.h:361-385 (t*q rows: binary image of alpha^(col*(2 row+1)))
+    std::vector<uint8_t> flat(static_cast<size_t>(t) * q * n);
+    uint32_t rows = 0;
+    detail::check(cc_get_H_alt(handle.get(), flat.data(), &rows), "cc_get_H_alt");
+    matrix<T> m(rows, n);
+    for (unsigned i = 0; i < rows; ++i)
+      for (unsigned j = 0; j < n; ++j) m.at(i).at(j) = T(flat[i * n + j]);
+    return m;
+  }
+
   // ---- encode, cyclic.h:289-311 ----
   template <typename InputSequence, typename OutputIterator> void encode(const InputSequence &a, OutputIterator &&out) const {
     if (a.size() != l) {
@@ -426,3 +441,39 @@ public:
 };
 
 }  // namespace cyclic
+
+// ---- soft_decision.h:220-295: the free functions min_sum<R, U>(H, y, tag) on any parity-check matrix ----
+// Returns (hard decision b, a-posteriori L, index of the accepting iteration) and throws decoding_failure when no
+// iteration satisfies the stop rule (soft_decision.h:199-201).  One launch per call: for throughput keep the
+// handle (cc_minsum_create) and feed cc_correct_soft_batch(_dev) with many frames.
+template <typename R, typename U = unsigned, typename Q, typename Tag>
+typename std::enable_if<std::is_base_of<soft_decision_tag, Tag>::value,
+                        std::tuple<std::vector<U>, std::vector<R>, unsigned>>::type
+min_sum(const matrix<U> &H, const std::vector<Q> &y, Tag, cc_stop_rule stop = CC_STOP_PARITY) {
+  const size_t rows = H.rows(), cols = H.columns();
+  if (y.size() != cols) throw std::runtime_error("min_sum: y does not match the matrix width");
+  std::vector<uint8_t> flat(rows * cols);
+  for (size_t i = 0; i < rows; ++i)
+    for (size_t j = 0; j < cols; ++j) flat[i * cols + j] = cyclic::detail::to_byte<U>::get(H.at(i).at(j));
+  cc_desc d;
+  cc_desc_init(&d);
+  d.algorithm = Tag::cc_alg;
+  d.iterations = Tag::iterations;
+  d.alpha = Tag::alpha;
+  d.beta = Tag::beta;
+  d.stop_rule = stop;
+  cc_code *c = nullptr;
+  cyclic::detail::check(cc_minsum_create(&d, flat.data(), static_cast<uint32_t>(rows), static_cast<uint32_t>(cols), &c),
+                        "cc_minsum_create");
+  std::unique_ptr<cc_code, cyclic::detail::code_deleter> guard(c);
+  std::vector<float> yf(y.begin(), y.end()), Lf(cols);
+  std::vector<uint8_t> b(cols);
+  uint16_t iter = 0;
+  int32_t status = 0;
+  cyclic::detail::check(cc_correct_soft_batch(c, yf.data(), nullptr, nullptr, b.data(), Lf.data(), &iter, &status, 1),
+                        "cc_correct_soft_batch");
+  if (status != CC_FRAME_OK) throw decoding_failure(cyclic::detail::failure_text(status));
+  std::vector<U> bu;
+  for (uint8_t v : b) bu.push_back(U(v));
+  return std::make_tuple(std::move(bu), std::vector<R>(Lf.begin(), Lf.end()), static_cast<unsigned>(iter));
+}

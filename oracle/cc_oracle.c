@@ -184,6 +184,8 @@ int orc_code_init(orc_code *c, int family, int q, int t, int mu, int step, int c
   c->mu = mu;
   c->step = step;
   c->coding = coding;
+  if (2 * t > 64) /* roots[64], S[64]: the oracle covers t <= 32 */
+    return -4;
   if (2 * t >= c->n)
     return -1;
   init_tables(c);
@@ -728,9 +730,35 @@ static int stop_test(int rule, const uint8_t *H, int k, int n, const uint8_t *b)
   return 1;
 }
 
+/* cyclic.h:361-385 */
+void orc_get_H_alt(const orc_code *c, uint8_t *H, int *rows) {
+  for (int r = 0; r < c->t; r++)
+    for (int bit = 0; bit < c->q; bit++)
+      for (int col = 0; col < c->n; col++) {
+        uint8_t v = from_power(c, (unsigned)(col * (2 * r + 1)));
+        H[((size_t)r * (size_t)c->q + (size_t)bit) * (size_t)c->n + (size_t)col] = (uint8_t)((v >> bit) & 1);
+      }
+  if (rows)
+    *rows = c->t * c->q;
+}
+
+static int minsum_core(const orc_code *c, const uint8_t *Hin, int k, int n, int variant, unsigned iterations,
+                       double alpha, double beta, int stop_rule, const float *yin, const uint16_t *erasures,
+                       int nerasures, uint8_t *b, float *L, unsigned *iter);
+
 int orc_minsum(const orc_code *c, int variant, unsigned iterations, double alpha, double beta, int stop_rule,
                const float *yin, const uint16_t *erasures, int nerasures, uint8_t *b, float *L, unsigned *iter) {
-  const int n = c->n, k = c->k;
+  return minsum_core(c, NULL, c->k, c->n, variant, iterations, alpha, beta, stop_rule, yin, erasures, nerasures, b, L, iter);
+}
+
+int orc_minsum_H(const uint8_t *H, int rows, int cols, int variant, unsigned iterations, double alpha, double beta,
+                 int stop_rule, const float *y, uint8_t *b, float *L, unsigned *iter) {
+  return minsum_core(NULL, H, rows, cols, variant, iterations, alpha, beta, stop_rule, y, NULL, 0, b, L, iter);
+}
+
+static int minsum_core(const orc_code *c, const uint8_t *Hin, int k, int n, int variant, unsigned iterations,
+                       double alpha, double beta, int stop_rule, const float *yin, const uint16_t *erasures,
+                       int nerasures, uint8_t *b, float *L, unsigned *iter) {
   ms_params P;
   ms_params_init(&P, variant, alpha, beta);
   uint8_t *H = (uint8_t *)malloc((size_t)k * (size_t)n);
@@ -739,7 +767,10 @@ int orc_minsum(const orc_code *c, int variant, unsigned iterations, double alpha
   float *cs = (float *)malloc((size_t)n * sizeof(float));
   float *y = (float *)malloc((size_t)n * sizeof(float));
   int status = ORC_FRAME_NOT_CONVERGED;
-  orc_get_H(c, H); /* rebuilt per call: cyclic.h:265 */
+  if (Hin)
+    memcpy(H, Hin, (size_t)k * (size_t)n);
+  else
+    orc_get_H(c, H); /* rebuilt per call: cyclic.h:265 */
   memcpy(y, yin, (size_t)n * sizeof(float));
   for (int e = 0; e < nerasures; e++)
     y[erasures[e]] = 0.0f; /* cyclic.h:259-262 */

@@ -90,6 +90,12 @@ void orc_extract(const orc_code *c, const uint8_t *cw /* n */, uint8_t *msg /* l
 int orc_minsum(const orc_code *c, int variant, unsigned iterations, double alpha, double beta, int stop_rule,
                const float *y, const uint16_t *erasures, int nerasures, uint8_t *b, float *L, unsigned *iter);
 
+/* cyclic::H_alt<T>() cyclic.h:361-385 (t*q rows x n), including from_power's exponent reduction mod 2^q */
+void orc_get_H_alt(const orc_code *c, uint8_t *H, int *rows);
+/* min_sum__ over a caller-supplied rows x n matrix (what min_sum<float,U>(matrix, y, tag) does) */
+int orc_minsum_H(const uint8_t *H, int rows, int cols, int variant, unsigned iterations, double alpha, double beta,
+                 int stop_rule, const float *y, uint8_t *b, float *L, unsigned *iter);
+
 /* Same algorithm, O(w) check-node update and no per-frame allocation; must be
  * bit-identical to orc_minsum (used to cross-check and as an optimised CPU
  * timing point). */

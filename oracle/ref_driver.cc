@@ -132,6 +132,9 @@ struct code_iface {
                        std::vector<uint8_t> &sigma) const = 0;
   virtual int minsum(int variant, unsigned iters, int utype, const float *y, uint8_t *b, float *L,
                      unsigned *iter) const = 0;
+  virtual std::vector<uint8_t> H_alt_u8() const = 0;
+  virtual int minsum_alt(int variant, unsigned iters, int utype, const float *y, uint8_t *b, float *L,
+                         unsigned *iter) const = 0;
 };
 
 /* Protected members (g, h, roots, k, l, dmin) live in the cyclic::cyclic<...>
@@ -355,6 +358,33 @@ template <typename PGZ, typename BM, typename EUK> struct code_impl : code_iface
     }
     for (const auto &s : sig)
       sigma.push_back(static_cast<uint8_t>(static_cast<unsigned>(s)));
+  }
+
+  std::vector<uint8_t> H_alt_u8() const override {
+    auto Hm = pgz.template H_alt<uint8_t>();
+    std::vector<uint8_t> out;
+    for (size_t r = 0; r < Hm.rows(); r++)
+      for (size_t c = 0; c < Hm.columns(); c++)
+        out.push_back(Hm.at(r).at(c));
+    return out;
+  }
+
+  /* min_sum over the alternative parity-check matrix cyclic.h:361-385 */
+  int minsum_alt(int variant, unsigned iters, int utype, const float *yin, uint8_t *b, float *L,
+                 unsigned *iter) const override {
+    std::vector<float> y(yin, yin + n);
+    if (utype == 0) {
+      auto res = run_iters<uint8_t>(iters, variant, pgz.template H_alt<uint8_t>(), y);
+      for (unsigned i = 0; i < n; i++) {
+        b[i] = std::get<0>(res)[i];
+        L[i] = std::get<1>(res)[i];
+      }
+      *iter = std::get<2>(res);
+    } else {
+      /* H_alt<ef_element<2,1>>() does not compile in the reference (cyclic.h:379: no push_back(bool)) */
+      throw std::invalid_argument("H_alt<gf2> is ill-formed in the reference");
+    }
+    return 0;
   }
 
   int minsum(int variant, unsigned iters, int utype, const float *yin, uint8_t *b, float *L,
@@ -584,6 +614,35 @@ API int ref_minsum_batch(int id, int variant, unsigned iters, int utype, const f
   auto t1 = std::chrono::steady_clock::now();
   if (seconds)
     *seconds = std::chrono::duration<double>(t1 - t0).count();
+  return ST_OK;
+}
+
+API int ref_get_H_alt(int id, uint8_t *out) {
+  auto c = get(id);
+  if (!c)
+    return ST_BAD_ARG;
+  auto H = c->H_alt_u8();
+  std::copy(H.begin(), H.end(), out);
+  return ST_OK;
+}
+
+API int ref_minsum_alt_batch(int id, int variant, unsigned iters, int utype, const float *y, size_t frames,
+                             uint8_t *b, float *L, unsigned *iter, int *status) {
+  auto c = get(id);
+  if (!c)
+    return ST_BAD_ARG;
+  std::vector<uint8_t> bt(c->n);
+  std::vector<float> Lt(c->n);
+  for (size_t f = 0; f < frames; f++) {
+    unsigned it = 0;
+    int st = guarded(nullptr, 0, [&] { c->minsum_alt(variant, iters, utype, y + f * c->n, bt.data(), Lt.data(), &it); });
+    status[f] = st;
+    iter[f] = st == ST_OK ? it : iters;
+    if (st == ST_OK) {
+      std::copy(bt.begin(), bt.end(), b + f * c->n);
+      std::copy(Lt.begin(), Lt.end(), L + f * c->n);
+    }
+  }
   return ST_OK;
 }
 

@@ -97,6 +97,31 @@ class Oracle:
         self.lib().orc_get_H(C.byref(self.c), _ptr(H))
         return H
 
+    def H_alt(self):
+        H = np.zeros((self.t * self.q, self.n), np.uint8)
+        rows = C.c_int()
+        self.lib().orc_get_H_alt(C.byref(self.c), _ptr(H), C.byref(rows))
+        return H[: rows.value]
+
+    @classmethod
+    def minsum_H(cls, H, variant, iterations, y, alpha=1.0, beta=0.0, stop=O2):
+        """min_sum__ over an explicit rows x cols matrix (no code involved)."""
+        H = np.ascontiguousarray(H, np.uint8)
+        rows, cols = H.shape
+        y = np.ascontiguousarray(y, np.float32).reshape(-1, cols)
+        B = y.shape[0]
+        b = np.zeros((B, cols), np.uint8)
+        L = np.zeros((B, cols), np.float32)
+        iters = np.zeros(B, np.uint32)
+        status = np.zeros(B, np.int32)
+        it = C.c_uint()
+        for i in range(B):
+            status[i] = cls.lib().orc_minsum_H(_ptr(H), rows, cols, variant, iterations, C.c_double(alpha),
+                                               C.c_double(beta), stop, _ptr(y[i]), _ptr(b[i]), _ptr(L[i]),
+                                               C.byref(it))
+            iters[i] = it.value
+        return b, L, iters, status
+
     def to_string(self, alg_name):
         buf = C.create_string_buffer(128)
         self.lib().orc_to_string(C.byref(self.c), alg_name.encode(), buf, 128)
@@ -292,6 +317,26 @@ class RefLib:
                                            C.byref(sec))
         assert rc == 0
         return out, st, sec.value
+
+    def H_alt(self, cid):
+        i = self.info(cid)
+        H = np.zeros((i["t"] * i["q"], i["n"]), np.uint8)
+        assert self.lib.ref_get_H_alt(cid, _ptr(H)) == 0
+        return H
+
+    def minsum_alt(self, cid, variant, iters, utype, y):
+        """min_sum<float, U>(code.H_alt<U>(), y, tag)"""
+        i = self.info(cid)
+        y = np.ascontiguousarray(y, np.float32).reshape(-1, i["n"])
+        B = y.shape[0]
+        b = np.zeros((B, i["n"]), np.uint8)
+        L = np.zeros((B, i["n"]), np.float32)
+        it = np.zeros(B, np.uint32)
+        st = np.zeros(B, np.int32)
+        rc = self.lib.ref_minsum_alt_batch(cid, variant, iters, utype, _ptr(y), C.c_size_t(B), _ptr(b), _ptr(L),
+                                           _ptr(it), _ptr(st))
+        assert rc == 0
+        return b, L, it, st
 
     def soft_class(self, selector, y, erasures=()):
         y = np.ascontiguousarray(y, np.float32)

@@ -108,6 +108,27 @@ int main() try {
       if (res.status[f] != CC_FRAME_OK || res.iters[f] != 0 || res.L[f * 15] != 0.7f) throw std::runtime_error("batch");
     std::printf("ok   batch of 1000 soft frames\n");
   }
+  {  // H_alt (cyclic.h:361-385) and the free min_sum<R, U>(H, y, tag) of soft_decision.h:220-295
+    cyclic::primitive_bch<4, errors<2>, min_sum_tag<10>> code;
+    const auto Ha = code.H_alt<uint8_t>();
+    if (Ha.rows() != 8 || Ha.columns() != 15) throw std::runtime_error("H_alt shape");
+    // row 0..3 = bits of alpha^col: alpha^0 = 1 -> column 0 is (1,0,0,0); alpha^1 = 2 -> column 1 is (0,1,0,0)
+    if (!Ha.at(0).at(0) || Ha.at(1).at(0) || Ha.at(0).at(1) || !Ha.at(1).at(1)) throw std::runtime_error("H_alt bits");
+    const std::vector<float> y({0.9f, 1.1f, -0.3f, 0.8f, 1.2f, 0.7f, 1.0f, -0.2f, 0.6f, 1.3f, 0.95f, 1.05f, 0.85f, 1.15f, 0.75f});
+    const auto viaH = min_sum<float, uint8_t>(code.H<uint8_t>(), y, min_sum_tag<10>());
+    expect_equal("free min_sum on H == code.correct", code.correct<uint8_t>(y), std::get<0>(viaH));
+    if (std::get<2>(viaH) != 0 || std::get<1>(viaH)[0] != 0.7f) throw std::runtime_error("free min_sum L / iteration");
+    const auto viaAlt = min_sum<float, uint8_t>(Ha, y, normalized_min_sum_tag<10, std::ratio<8, 10>>());
+    expect_equal("free min_sum on H_alt", std::vector<uint8_t>(15, 0), std::get<0>(viaAlt));
+    matrix<uint8_t> one(0, 3);
+    one.push_back({1, 1, 0});
+    // under the published stop rule (integer dot product) the word 110 is never accepted
+    expect_failure("free min_sum, never accepted", [&] {
+      min_sum<float, uint8_t>(one, std::vector<float>({-5.0f, -5.0f, 1.0f}), min_sum_tag<3>(), CC_STOP_PUBLISHED);
+    });
+    const auto ok110 = min_sum<float, uint8_t>(one, std::vector<float>({-5.0f, -5.0f, 1.0f}), min_sum_tag<3>());
+    expect_equal("free min_sum, GF(2) parity rule", std::vector<uint8_t>({1, 1, 0}), std::get<0>(ok110));
+  }
   std::printf("ALL OK\n");
   return 0;
 } catch (const std::exception &e) {

@@ -12,6 +12,8 @@ Files
   exercises.json      the known-answer vectors of src/exercises.c++ (tasks 6.1-6.10) with the reference's results
   encode_<code>.npz   msg -> codeword
   hard_<code>.npz     received words with 0..t+2 errors -> corrected word / status, for PGZ, BM, EUKLID
+  minsum_alt.npz      H_alt<uint8_t>() of three codes and min_sum<float,uint8_t>(H_alt, y, tag) on it (O0/O1;
+                      H_alt<gf2> is ill-formed in the reference, so there is no O2 leg)
   minsum_<code>.npz   LLR frames -> b, L, iteration, status for every variant x stop rule O0/O1/O2
 """
 import json
@@ -102,8 +104,37 @@ def corrupt(rng, o, cw, nerr):
     return b
 
 
+def alt_golden(ref0, ref1):
+    """cyclic::H_alt (cyclic.h:361-385) and min-sum over it.  Only all-zero codewords can be accepted under
+    O1, so the frames are noisy all-zero words plus a few random codewords (those fail)."""
+    d = {}
+    for cid, iters, frames, ebno in ((0, 10, 48, 3.0), (1, 10, 48, 3.0), (5, 20, 32, 4.0), (6, 20, 8, 6.0)):
+        fam, q, t = REF_CODES[cid]
+        o = Oracle(fam, q, t)
+        rng = np.random.default_rng(3000 + cid)
+        c = np.zeros((frames, o.n), np.uint8)
+        c[-4:] = ref0.encode(cid, rng.integers(0, 2, (4, o.l)).astype(np.uint8))
+        y = awgn_llr(rng, c, o.l / o.n, ebno)
+        pre = "c%d_" % cid
+        d[pre + "H"] = np.packbits(ref0.H_alt(cid), axis=1)
+        d[pre + "y"] = y
+        d[pre + "iterations"] = np.array(iters)
+        for v in sorted(REF_VARIANTS):
+            for rule, lib in (("o0", ref0), ("o1", ref1)):
+                b, L, it, st = lib.minsum_alt(cid, v, iters, 0, y)
+                key = pre + "v%d_%s" % (v, rule)
+                d[key + "_b"] = np.packbits(b, axis=1)
+                d[key + "_L"] = L
+                d[key + "_it"] = it.astype(np.uint16)
+                d[key + "_st"] = st.astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, "minsum_alt.npz"), **d)
+
+
 def main():
     ref0, ref1 = RefLib.get(0), RefLib.get(1)
+    if sys.argv[1:] == ["alt"]:
+        return alt_golden(ref0, ref1)
+    alt_golden(ref0, ref1)
     with open(os.path.join(HERE, "constants.json"), "w") as f:
         json.dump(constants(ref0), f, indent=1)
     with open(os.path.join(HERE, "exercises.json"), "w") as f:

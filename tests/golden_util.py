@@ -40,3 +40,25 @@ def minsum_cases(cid):
             b = np.unpackbits(d[key + "_b"], axis=1)[:, :width]
             yield v, REF_VARIANTS[v], rid, b, d[key + "_L"], d[key + "_it"].astype(np.uint32), d[key + "_st"].astype(
                 np.int32)
+
+
+ALT_CIDS = (0, 1, 5, 6)
+
+
+def minsum_alt_cases(cid):
+    """(H_alt, y, iterations, iterator of (variant_id, (oracle_variant, alpha, beta), rule_id, b, L, it, st))."""
+    d = np.load(os.path.join(GOLDEN, "minsum_alt.npz"), allow_pickle=False)
+    pre = "c%d_" % cid
+    y = d[pre + "y"]
+    width = y.shape[1]
+    H = np.unpackbits(d[pre + "H"], axis=1)[:, :width]
+
+    def cases():
+        for v in sorted(REF_VARIANTS):
+            for rule in ("o0", "o1"):
+                key = pre + "v%d_%s" % (v, rule)
+                b = np.unpackbits(d[key + "_b"], axis=1)[:, :width]
+                yield v, REF_VARIANTS[v], RULES[rule], b, d[key + "_L"], d[key + "_it"].astype(np.uint32), d[
+                    key + "_st"].astype(np.int32)
+
+    return H, y, int(d[pre + "iterations"]), cases()

@@ -169,3 +169,98 @@ def test_minsum_other_geometries(q, t):
         code = cc.primitive_bch(q, cc.errors(t), TAG[ov](12, alpha, beta), stop_rule=rule)
         res = code.correct_batch(y, want_L=True)
         check(res, *o.minsum(ov, 12, y, alpha, beta, rule, fast=True), tag=(q, t, v, rule))
+
+
+@pytest.mark.parametrize("cid", G.ALT_CIDS)
+def test_minsum_h_alt_golden(cid):
+    """min_sum over cyclic::H_alt (cyclic.h:361-385) supplied through cc_code_create_with_H, against the
+    reference's committed outputs (O0/O1) and the oracle (failed frames, and O2 which the reference cannot
+    instantiate for H_alt)."""
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t)
+    H, y, iters, cases = G.minsum_alt_cases(cid)
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in cases:
+        code = cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta), stop_rule=rule, H=H)
+        res = code.correct_batch(y, want_L=True)
+        ok = gst == 0
+        assert np.array_equal(res["status"] != 0, gst != 0), (v, rule)
+        assert np.array_equal(res["out"][ok], gb[ok]) and np.array_equal(res["iters"][ok], git[ok]), (v, rule)
+        assert np.allclose(res["L"][ok], gL[ok], rtol=0, atol=1e-5), (v, rule)
+        check(res, *o.minsum_H(H, ov, iters, y, alpha, beta, rule), tag=(v, rule))
+    rng = np.random.default_rng(cid)
+    cw = o.encode(rng.integers(0, 2, (40, o.l)).astype(np.uint8))
+    y2 = awgn_llr(rng, cw, o.l / o.n, 6.0)
+    for ov, alpha, beta in ((0, 1.0, 0.0), (1, 0.75, 0.0), (4, 1.0, 0.0)):
+        code = cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta), stop_rule=O2, H=H)
+        check(code.correct_batch(y2, want_L=True), *o.minsum_H(H, ov, iters, y2, alpha, beta, O2), tag=("o2", ov))
+
+
+def test_minsum_custom_matrix():
+    """A caller-supplied matrix equal to H() must reproduce the built-in path; an irregular sparse matrix
+    (row-combined H, ragged row weights, an all-zero row and an all-zero column block) must match the oracle."""
+    rng = np.random.default_rng(99)
+    for q, t, iters in ((4, 2, 10), (6, 3, 10), (8, 3, 20)):
+        o = Oracle(BCH, q, t)
+        cw = o.encode(rng.integers(0, 2, (70, o.l)).astype(np.uint8))
+        y = awgn_llr(rng, cw, o.l / o.n, 5.0)
+        builtin = cc.primitive_bch(q, cc.errors(t), cc.min_sum_tag(iters))
+        custom = cc.primitive_bch(q, cc.errors(t), cc.min_sum_tag(iters), H=builtin.H())
+        assert custom.kernel_info()["kernel"].startswith("minsum_generic")
+        a, b = builtin.correct_batch(y, want_L=True), custom.correct_batch(y, want_L=True)
+        for key in ("out", "L", "iters", "status"):
+            assert np.array_equal(a[key], b[key]), (q, key)
+        H = o.H().copy()
+        H[1] ^= H[0]
+        H[-1] = 0
+        H = np.concatenate([H, H[2:3] ^ H[4:5]])
+        for ov, alpha, beta, rule in ((0, 1.0, 0.0, O2), (2, 1.0, 0.15, O2), (3, 1.0, 0.0, O1), (5, 0.75, 2.25, O2)):
+            code = cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta), stop_rule=rule, H=H)
+            check(code.correct_batch(y, want_L=True), *o.minsum_H(H, ov, iters, y, alpha, beta, rule), tag=(q, ov))
+
+
+@pytest.mark.parametrize("rows,cols,density", [(5, 9, 0.4), (8, 16, 0.3), (12, 31, 0.2), (30, 64, 0.1), (40, 100, 0.08),
+                                               (64, 128, 0.05), (33, 129, 0.06), (100, 200, 0.03), (150, 256, 0.03),
+                                               (1, 256, 0.5), (230, 256, 0.02)])
+def test_min_sum_free_function_any_matrix(rows, cols, density):
+    """cc_minsum_create = the free min_sum<R,U>(H, y, tag) (soft_decision.h:220-295) on arbitrary matrices:
+    ragged row / column weights, empty rows and columns, widths that are not 2^q - 1."""
+    rng = np.random.default_rng(rows * 1000 + cols)
+    H = (rng.random((rows, cols)) < density).astype(np.uint8)
+    if rows > 3:
+        H[2] = 0
+    H[:, cols // 2] = 0
+    o = Oracle
+    y = (1.0 + 0.9 * rng.standard_normal((67, cols))).astype(np.float32)  # noisy all-zero word (always a codeword)
+    y[0, : min(4, cols)] = [0.0, -0.0, 0.5, -0.5][: min(4, cols)]
+    for ov, alpha, beta, rule in ((0, 1.0, 0.0, O2), (1, 0.8, 0.0, O1), (2, 1.0, 0.15, O2), (3, 1.0, 0.0, O2),
+                                  (4, 1.0, 0.0, O0), (5, 0.75, 2.25, O2)):
+        dec = cc.min_sum_decoder(H, TAG[ov](15, alpha, beta), stop_rule=rule)
+        res = dec.correct_batch(y, want_L=True)
+        check(res, *o.minsum_H(H, ov, 15, y, alpha, beta, rule), tag=(rows, cols, ov))
+    ok = np.flatnonzero(res["status"] == 0)
+    if len(ok):
+        b, L, it = cc.min_sum(H, y[ok[0]], TAG[5](15, 0.75, 2.25))
+        assert np.array_equal(b, res["out"][ok[0]]) and np.array_equal(L, res["L"][ok[0]]) and it == res["iters"][ok[0]]
+    bad = np.flatnonzero(res["status"] != 0)
+    if len(bad):
+        with pytest.raises(cc.decoding_failure):
+            cc.min_sum(H, y[bad[0]], TAG[5](15, 0.75, 2.25))
+
+
+@pytest.mark.parametrize("q,t,ov,iters", [(8, 18, 4, 10), (8, 30, 0, 10), (8, 31, 3, 5), (7, 14, 4, 10)])
+def test_minsum_long_low_rate_codes(q, t, ov, iters):
+    """Codes whose k x n message state exceeds the 160 KiB of LDS run the generic kernel with its state in HBM
+    (minsum.hip GSTATE); results must not depend on where the state lives."""
+    o = Oracle(BCH, q, t)
+    rng = np.random.default_rng(q * 100 + t)
+    cw = o.encode(rng.integers(0, 2, (300, o.l)).astype(np.uint8))
+    y = awgn_llr(rng, cw, o.l / o.n, 8.0)
+    alpha, beta = 1.0, 0.0
+    code = cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta))
+    info = code.kernel_info()
+    assert ("[state in HBM]" in info["kernel"]) == (q == 8), info
+    res = code.correct_batch(y, want_L=True)
+    sub = slice(0, 24)  # the dense oracle is O(k n) per row here
+    ob, oL, oit, ost = o.minsum(ov, iters, y[sub], alpha, beta, O2, fast=True)
+    check({k: v[sub] for k, v in res.items()}, ob, oL, oit, ost, (q, t))
+    assert (res["status"] == 0).any() and (res["status"] != 0).any()  # both outcomes exercised

@@ -96,3 +96,44 @@ def test_no_cpu_fallback():
         with pytest.raises(cc.CcError) as e:
             cc.primitive_bch(4, cc.errors(2))  # default device: needs a GPU
         assert e.value.status == capi.ERR_NO_DEVICE
+
+
+def test_h_alt_and_custom_matrix_arguments():
+    """cc_get_H_alt needs no device; cc_code_create_with_H validates like the reference's free min_sum would."""
+    for cid in G.ALT_CIDS:
+        fam, q, t = REF_CODES[cid]
+        code = cc.primitive_bch(q, cc.errors(t), device=capi.DEVICE_NONE)
+        H, _, _, _ = G.minsum_alt_cases(cid)
+        assert np.array_equal(code.H_alt(), H)
+    H = cc.primitive_bch(4, cc.errors(2), device=capi.DEVICE_NONE).H_alt()
+    soft = cc.primitive_bch(4, cc.errors(2), cc.min_sum_tag(10), device=capi.DEVICE_NONE, H=H)
+    assert soft.n == 15 and soft.to_string() == "(15, 7, 5)-MS"
+    with pytest.raises(capi.CcError):  # a matrix only makes sense for the min-sum family
+        cc.primitive_bch(4, cc.errors(2), cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE, H=H)
+    with pytest.raises(ValueError):  # wrong width
+        cc.primitive_bch(4, cc.errors(2), cc.min_sum_tag(10), device=capi.DEVICE_NONE, H=H[:, :14])
+    with pytest.raises(capi.CcError):  # non-binary entries
+        cc.primitive_bch(4, cc.errors(2), cc.min_sum_tag(10), device=capi.DEVICE_NONE, H=H * 2)
+
+
+def test_min_sum_decoder_host_logic():
+    """cc_minsum_create: the free min_sum(H, y, tag) -- a matrix, no code."""
+    rng = np.random.default_rng(5)
+    H = (rng.random((20, 100)) < 0.1).astype(np.uint8)
+    dec = cc.min_sum_decoder(H, cc.normalized_min_sum_tag(20, 0.8), device=capi.DEVICE_NONE)
+    assert (dec.n, dec.k, dec.l) == (100, 20, 80) and dec.to_string() == "20x100-NMS"
+    assert np.array_equal(dec.H(), H)
+    assert dec.kernel_info()["kernel"] == "minsum_generic_kernel<C=2,W=64>"
+    assert cc.min_sum_decoder(H[:, :15], device=capi.DEVICE_NONE).kernel_info()["frames_per_workgroup"] == 4
+    for call in (lambda: dec.encode_batch(np.zeros((1, 80), np.uint8)), dec.H_alt,
+                 lambda: dec.extract_batch(np.zeros((1, 100), np.uint8))):
+        with pytest.raises(capi.CcError):
+            call()
+    with pytest.raises(capi.CcError):  # no CPU fallback here either
+        dec.correct_batch(np.ones((1, 100), np.float32))
+    with pytest.raises(capi.CcError):
+        cc.min_sum_decoder(np.zeros((4, 257), np.uint8), device=capi.DEVICE_NONE)
+    with pytest.raises(capi.CcError):
+        cc.min_sum_decoder(H, cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE)
+    with pytest.raises(capi.CcError):
+        cc.min_sum_decoder(H * 3, device=capi.DEVICE_NONE)

@@ -70,23 +70,23 @@ from test_montecarlo_dist import StubBackend, StubCode
 dist.init_process_group("gloo")
 sim = awgn_simulation(StubCode(), backend=StubBackend(), max_samples=50000)
 res = [(r["ebno"], r["frames"], r["word_errors"], r["bit_errors"]) for r in sim()]
-print("RESULT%%d %%s" %% (dist.get_rank(), json.dumps(res)))
+with open(os.path.join(%(out)r, "rank%%d.json" %% dist.get_rank()), "w") as f:  # one file per rank: shared stdout interleaves
+    json.dump(res, f)
 dist.barrier(); dist.destroy_process_group()
 """
 
 
 def test_two_ranks_equal_one_rank(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     got = {}
-    for line in out.stdout.splitlines():
-        if line.startswith("RESULT"):
-            got[int(line[6])] = json.loads(line.split(" ", 1)[1])
-    assert set(got) == {0, 1}
+    for rank in (0, 1):
+        with open(tmp_path / ("rank%d.json" % rank)) as f:
+            got[rank] = json.load(f)
     single = [list(x) for x in run_single()]
     assert got[0] == single and got[1] == single  # every rank holds the same reduced totals

@@ -100,3 +100,17 @@ def test_minsum_golden(cid):
         ok = st == 0
         assert np.array_equal(st != 0, gst[sub] != 0)
         assert np.array_equal(b[ok], gb[sub][ok]) and np.array_equal(L[ok], gL[sub][ok])
+
+
+@pytest.mark.parametrize("cid", G.ALT_CIDS)
+def test_minsum_alt_golden(cid):
+    """H_alt and min-sum over it against the reference's committed outputs."""
+    o = oracle_for(cid)
+    H, y, iters, cases = G.minsum_alt_cases(cid)
+    assert np.array_equal(o.H_alt(), H)
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in cases:
+        b, L, it, st = o.minsum_H(H, ov, iters, y, alpha, beta, rule)
+        assert np.array_equal(st != 0, gst != 0), (v, rule)
+        ok = st == 0
+        assert np.array_equal(b[ok], gb[ok]) and np.array_equal(it[ok], git[ok]), (v, rule)
+        assert np.array_equal(L[ok], gL[ok]), (v, rule)

@@ -282,3 +282,34 @@ def test_survey_appendix_b2_kat(ref_libs):
     assert o.minsum(ov, 10, y2, a, bt, O1)[3][0] == 1  # decoding_failure
     b, _, _, _ = o.minsum(0, 10, y2, stop=O0)
     assert "".join(map(str, b[0])) == "010001001100000"
+
+
+@pytest.mark.parametrize("cid", sorted(REF_CODES))
+def test_h_alt_matches_reference(ref_libs, cid):
+    """cyclic::H_alt<uint8_t>() (cyclic.h:361-385), from_power's exponent reduction mod 2^q included."""
+    ref0, _ = ref_libs
+    assert np.array_equal(oracle_for(cid).H_alt(), ref0.H_alt(cid))
+
+
+@pytest.mark.parametrize("cid,iters,ebno,frames", [(0, 10, 3.0, 96), (1, 20, 3.0, 96), (12, 20, 3.0, 64),
+                                                   (5, 20, 4.0, 48), (13, 10, 4.0, 32), (6, 20, 6.0, 8)])
+def test_minsum_on_h_alt_matches_reference(ref_libs, cid, iters, ebno, frames):
+    """min_sum<float, uint8_t>(code.H_alt<uint8_t>(), y, tag): every variant, stop rules O0 and O1
+    (H_alt<gf2> is ill-formed in the reference, so O2 has no reference leg)."""
+    ref0, ref1 = ref_libs
+    o = oracle_for(cid)
+    H = o.H_alt()
+    rng = np.random.default_rng(7000 + cid)
+    y = awgn_llr(rng, np.zeros((frames, o.n), np.uint8), o.l / o.n, ebno)  # only 0 can be accepted under O1 (F2)
+    accepted = 0
+    for v, (ov, alpha, beta) in REF_VARIANTS.items():
+        for lib, rule in ((ref0, O0), (ref1, O1)):
+            b, L, it, st = lib.minsum_alt(cid, v, iters, 0, y)
+            ob, oL, oit, ost = o.minsum_H(H, ov, iters, y, alpha, beta, rule)
+            assert np.array_equal(st != 0, ost != 0), (v, rule)
+            ok = st == 0
+            assert np.array_equal(b[ok], ob[ok]) and np.array_equal(it[ok], oit[ok]), (v, rule)
+            assert np.array_equal(L[ok], oL[ok]), (v, rule)
+            if rule == O1:
+                accepted += int(ok.sum())
+    assert accepted > 0
