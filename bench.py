@@ -75,18 +75,36 @@ def secondary_workloads(torch, cc, capi, dev):
     ms = timed(lambda: lib.cc_correct_soft_batch_dev(code._h, vp(y), None, None, vp(hard), None, vp(it), vp(st), B, sh))
     out["bch63_45_ms10_4dB_2^16"] = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms,
                                      "converged_fraction": float((st == 0).float().mean())}
-    # headline code at 6 dB (SURVEY section 8d asks for 4 dB and 6 dB)
-    code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20))
+    # headline code at other operating points (4 dB and 6 dB, a random-codeword variant under
+    # O2, and the as-shipped stop rule O0 = exactly one iteration per frame)
     B = 1 << 20
-    y = torch.empty((B, 255), dtype=torch.float32, device=dev).normal_(1.0, float(code.sigma(6.0)), generator=g)
+    y = torch.empty((B, 255), dtype=torch.float32, device=dev)
     hard = torch.empty((B, 255), dtype=torch.uint8, device=dev)
     it = torch.empty(B, dtype=torch.int16, device=dev)
     st = torch.empty(B, dtype=torch.int32, device=dev)
-    ms = timed(lambda: lib.cc_correct_soft_batch_dev(code._h, vp(y), None, None, vp(hard), None, vp(it), vp(st), B, sh))
-    run = torch.where(st == 0, it.to(torch.int32) + 1, it.to(torch.int32))
-    out["bch255_231_ms20_6dB_2^20"] = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms,
-                                       "mean_iterations_run": float(run.float().mean()),
-                                       "achieved_GBs": 1281 * B / (ms * 1e-3) / 1e9}
+
+    def headline_point(key, ebno, stop_rule=2, random_codewords=False):
+        code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20), stop_rule=stop_rule)
+        y.normal_(0.0, float(code.sigma(ebno)), generator=g)
+        if random_codewords:  # y = (1 - 2c) + sigma N
+            msg = torch.randint(0, 2, (B, code.l), dtype=torch.uint8, device=dev, generator=g)
+            cw = code.encode_batch(msg)
+            y.add_(1.0 - 2.0 * cw.to(torch.float32))
+        else:
+            y.add_(1.0)
+        ms = timed(lambda: lib.cc_correct_soft_batch_dev(code._h, vp(y), None, None, vp(hard), None, vp(it), vp(st),
+                                                         B, sh))
+        run = torch.where(st == 0, it.to(torch.int32) + 1, it.to(torch.int32))
+        res = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms, "mean_iterations_run": float(run.float().mean()),
+               "converged_fraction": float((st == 0).float().mean()), "achieved_GBs": 1281 * B / (ms * 1e-3) / 1e9}
+        if random_codewords:
+            res["decoded_equals_sent_fraction"] = float((hard == cw).all(dim=1).float().mean())
+        out[key] = res
+
+    headline_point("bch255_231_ms20_6dB_2^20", 6.0)
+    headline_point("bch255_231_ms20_8dB_2^20", 8.0)
+    headline_point("bch255_231_ms20_4dB_random_codewords_2^20", 4.0, random_codewords=True)
+    headline_point("bch255_231_ms20_4dB_stop_rule_O0_as_shipped_2^20", 4.0, stop_rule=0)
     del y, hard
     # configs[3]
     rs = cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag())
@@ -225,10 +243,24 @@ def main():
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # attainable HBM bandwidth on this box: device-to-device copy of the LLR batch (read + write bytes)
+    scratch = torch.empty_like(y)
+    scratch.copy_(y)
+    torch.cuda.synchronize()
+    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ca.record(stream)
+    for _ in range(5):
+        scratch.copy_(y)
+    cb.record(stream)
+    torch.cuda.synchronize()
+    copy_gbs = 2 * y.numel() * 4 * 5 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+    del scratch
+
     it_host = iters.to(torch.int32)
     conv = int((status == 0).sum().item())
     iters_run = torch.where(status == 0, it_host + 1, it_host)  # iterations actually executed
     mean_iters = float(iters_run.float().mean().item())
+    histogram = torch.bincount(iters_run.to(torch.int64), minlength=args.iterations + 1).tolist()
 
     if rank == 0:
         frames_per_s = world * B * args.steps / elapsed
@@ -257,12 +289,14 @@ def main():
                             % (args.iterations, args.stop_rule, args.ebno, sigma, args.batch_log2),
                 "frames_per_gpu": B, "n": n, "iterations_max": args.iterations,
                 "mean_iterations_run": mean_iters, "converged_fraction": conv / B,
+                "iterations_run_histogram": histogram,  # index = iterations executed by a frame (rank 0's shard)
                 "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name.value.decode(), args.batch_log2),
                 "kernel": name.value.decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bytes_per_frame,
+                "measured_copy_GBs": copy_gbs,  # attainable HBM rate on this box (d2d copy, read + write)
                 "note": "path is VALU-issue bound, not HBM bound (SURVEY F4): %.1f min-sum iterations per frame on average"
                         % mean_iters,
             },

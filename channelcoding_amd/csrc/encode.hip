@@ -120,6 +120,60 @@ extract_division_kernel(const uint8_t *__restrict__ cw, uint8_t *__restrict__ ms
   }
 }
 
+// multiplication_tag: a = b / g (cyclic.h:42-46), the quotient of the long division by the monic generator.
+// One wavefront per frame; the running remainder lives in LDS.  Step i reads the uniform coefficient c of
+// x^i and subtracts c * g * x^(i-k) on lanes j < k; position i itself is left untouched, so after the last
+// step rem[k + j] holds quotient coefficient j.  (LDS operations of one wave execute in order.)
+__global__ void __launch_bounds__(256)
+extract_multiplication_kernel(const AlgebraicTables *__restrict__ T, const uint8_t *__restrict__ cw,
+                              uint8_t *__restrict__ msg, unsigned long long B) {
+  __shared__ uint8_t ex[512];
+  __shared__ uint8_t lg[256];
+  __shared__ uint8_t rem[4][256];
+  const int n = T->n, k = T->k, l = T->l;
+  for (int i = threadIdx.x; i < 512; i += 256) ex[i] = T->exp[i];
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t lgg[4];
+  bool gnz[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = lane + 64 * c;
+    const uint32_t gj = j < k ? T->g[j] : 0u;
+    gnz[c] = gj != 0;
+    lgg[c] = lg[gj];
+  }
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int p = lane + 64 * c;
+      rem[wid][p] = p < n ? static_cast<uint8_t>(cw[f * n + p] & n) : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = n - 1; i >= k; --i) {
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(rem[wid][i]);
+      if (c0 != 0) {
+        const uint32_t lc = lg[c0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = lane + 64 * c;
+          if (j < k && gnz[c]) rem[wid][i - k + j] ^= ex[lc + lgg[c]];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      if (j < l) msg[f * l + j] = rem[wid][k + j];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 // PT[i][j] = coefficient i of x^(k+j) mod g  (i < k, j < l), row-major k x l
@@ -161,8 +215,13 @@ int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size
 int launch_extract(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, hipStream_t stream) {
   if (B == 0) return CC_OK;
   if (code->desc.coding == CC_CODING_MULTIPLICATION) {
-    set_last_error("message extraction for multiplication_tag (polynomial division by g) is not on the device path yet");
-    return CC_ERR_UNSUPPORTED;
+    const unsigned long long blocks_needed = (B + 3) / 4;
+    const unsigned long long cap = static_cast<unsigned long long>(code->num_cus) * 8;
+    hipLaunchKernelGGL(extract_multiplication_kernel, dim3(static_cast<int>(blocks_needed < cap ? blocks_needed : cap)),
+                       dim3(256), 0, stream, code->d_alg, d_cw, d_msg, static_cast<unsigned long long>(B));
+    hipError_t em = hipGetLastError();
+    if (em != hipSuccess) return hip_fail(em, "extract kernel launch");
+    return CC_OK;
   }
   const unsigned long long total = static_cast<unsigned long long>(B) * code->tab.l;
   const unsigned long long want = (total + 255) / 256;

@@ -132,6 +132,8 @@ struct code_iface {
                        std::vector<uint8_t> &sigma) const = 0;
   virtual int minsum(int variant, unsigned iters, int utype, const float *y, uint8_t *b, float *L,
                      unsigned *iter) const = 0;
+  virtual void encode_mult(const uint8_t *msg, uint8_t *cw) const = 0;
+  virtual void decode_mult(const uint8_t *cw, uint8_t *msg) const = 0;
   virtual std::vector<uint8_t> H_alt_u8() const = 0;
   virtual int minsum_alt(int variant, unsigned iters, int utype, const float *y, uint8_t *b, float *L,
                          unsigned *iter) const = 0;
@@ -281,6 +283,29 @@ template <typename PGZ, typename BM, typename EUK> struct code_impl : code_iface
     if (out.size() != n)
       throw std::logic_error("encode produced wrong length");
     std::copy(out.begin(), out.end(), cw);
+  }
+
+  /* the free functions of cyclic.h:29-33 and :42-46 with this code's generator: what a code instantiated with
+   * Coding = multiplication_tag runs inside encode() (:303) and decode() (:318-319) */
+  void encode_mult(const uint8_t *msg, uint8_t *cw) const override {
+    Polynomial a;
+    for (unsigned i = 0; i < l; i++)
+      a.push_back(Element(msg[i]));
+    auto enc = ::cyclic::encode(pgz.G(), a, ::cyclic::multiplication_tag());
+    if (enc.size() > n)
+      throw std::logic_error("encode produced wrong length");
+    std::fill(cw, cw + n, 0); /* fill_n(out, n - enc.size(), 0), cyclic.h:310 */
+    for (size_t i = 0; i < enc.size(); i++)
+      cw[i] = static_cast<uint8_t>(static_cast<unsigned>(enc[i]));
+  }
+  void decode_mult(const uint8_t *cw, uint8_t *msg) const override {
+    Polynomial b;
+    for (unsigned i = 0; i < n; i++)
+      b.push_back(Element(cw[i]));
+    auto dec = ::cyclic::decode(pgz.G(), b, ::cyclic::multiplication_tag());
+    std::fill(msg, msg + l, 0); /* fill_n(back_inserter(r), l - b_.size(), 0), cyclic.h:325 */
+    for (size_t i = 0; i < dec.size() && i < l; i++)
+      msg[i] = static_cast<uint8_t>(static_cast<unsigned>(dec[i]));
   }
 
   template <typename Seq> void correct_any(int alg, const Seq &b, const std::vector<unsigned> &er, uint8_t *out) const {
@@ -529,6 +554,20 @@ API int ref_encode(int id, const uint8_t *msg, uint8_t *cw, char *what, int what
   if (!c)
     return ST_BAD_ARG;
   return guarded(what, whatlen, [&] { c->encode(msg, cw); });
+}
+
+API int ref_encode_mult(int id, const uint8_t *msg, uint8_t *cw, char *what, int whatlen) {
+  auto c = get(id);
+  if (!c)
+    return ST_BAD_ARG;
+  return guarded(what, whatlen, [&] { c->encode_mult(msg, cw); });
+}
+
+API int ref_decode_mult(int id, const uint8_t *cw, uint8_t *msg, char *what, int whatlen) {
+  auto c = get(id);
+  if (!c)
+    return ST_BAD_ARG;
+  return guarded(what, whatlen, [&] { c->decode_mult(cw, msg); });
 }
 
 API int ref_correct_u8(int id, int alg, const uint8_t *in, const unsigned *er, int ne, uint8_t *out, char *what,

@@ -258,6 +258,26 @@ class RefLib:
             assert st == 0, w.value
         return cw
 
+    def encode_mult(self, cid, msg):
+        """::cyclic::encode(g, a, multiplication_tag) zero-padded to n (cyclic.h:29-33, :303-310)."""
+        i = self.info(cid)
+        msg = np.ascontiguousarray(msg, np.uint8).reshape(-1, i["l"])
+        cw = np.zeros((msg.shape[0], i["n"]), np.uint8)
+        w = C.create_string_buffer(256)
+        for f in range(msg.shape[0]):
+            assert self.lib.ref_encode_mult(cid, _ptr(msg[f]), _ptr(cw[f]), w, 256) == 0, w.value
+        return cw
+
+    def decode_mult(self, cid, cw):
+        """::cyclic::decode(g, b, multiplication_tag) = b / g zero-padded to l (cyclic.h:42-46, :318-325)."""
+        i = self.info(cid)
+        cw = np.ascontiguousarray(cw, np.uint8).reshape(-1, i["n"])
+        msg = np.zeros((cw.shape[0], i["l"]), np.uint8)
+        w = C.create_string_buffer(256)
+        for f in range(cw.shape[0]):
+            assert self.lib.ref_decode_mult(cid, _ptr(cw[f]), _ptr(msg[f]), w, 256) == 0, w.value
+        return msg
+
     def correct(self, cid, alg, frames, erasures=(), decode=False):
         """Returns out (B, n or l) u8, status (B,), messages list."""
         i = self.info(cid)

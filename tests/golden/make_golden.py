@@ -12,6 +12,7 @@ Files
   exercises.json      the known-answer vectors of src/exercises.c++ (tasks 6.1-6.10) with the reference's results
   encode_<code>.npz   msg -> codeword
   hard_<code>.npz     received words with 0..t+2 errors -> corrected word / status, for PGZ, BM, EUKLID
+  mult.npz            multiplication_tag: c = a*g and a = b/g (also for words that are not codewords)
   minsum_alt.npz      H_alt<uint8_t>() of three codes and min_sum<float,uint8_t>(H_alt, y, tag) on it (O0/O1;
                       H_alt<gf2> is ill-formed in the reference, so there is no O2 leg)
   minsum_<code>.npz   LLR frames -> b, L, iteration, status for every variant x stop rule O0/O1/O2
@@ -130,11 +131,36 @@ def alt_golden(ref0, ref1):
     np.savez_compressed(os.path.join(HERE, "minsum_alt.npz"), **d)
 
 
+def mult_golden(ref0):
+    """multiplication_tag coding (cyclic.h:29-33, :42-46): c = a g, a = b / g."""
+    d = {}
+    for cid, frames in ((0, 64), (5, 48), (6, 32), (8, 64), (9, 48), (10, 24)):
+        fam, q, t = REF_CODES[cid]
+        o = Oracle(fam, q, t)
+        rng = np.random.default_rng(4000 + cid)
+        hi = 2 if fam == BCH else 1 << q
+        msg = rng.integers(0, hi, (frames, o.l)).astype(np.uint8)
+        msg[0] = 0
+        msg[1] = hi - 1
+        msg[2, -3:] = 0  # short quotient: decode pads with zeros
+        cw = ref0.encode_mult(cid, msg)
+        rx = cw.copy()  # arbitrary words: the quotient ignores the remainder
+        for f in range(frames // 2, frames):
+            rx[f] = rng.integers(0, hi, o.n)
+        pre = "c%d_" % cid
+        d[pre + "msg"], d[pre + "cw"], d[pre + "rx"] = msg, cw, rx
+        d[pre + "quot"] = ref0.decode_mult(cid, rx)
+    np.savez_compressed(os.path.join(HERE, "mult.npz"), **d)
+
+
 def main():
     ref0, ref1 = RefLib.get(0), RefLib.get(1)
     if sys.argv[1:] == ["alt"]:
         return alt_golden(ref0, ref1)
+    if sys.argv[1:] == ["mult"]:
+        return mult_golden(ref0)
     alt_golden(ref0, ref1)
+    mult_golden(ref0)
     with open(os.path.join(HERE, "constants.json"), "w") as f:
         json.dump(constants(ref0), f, indent=1)
     with open(os.path.join(HERE, "exercises.json"), "w") as f:

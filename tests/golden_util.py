@@ -62,3 +62,13 @@ def minsum_alt_cases(cid):
                     key + "_st"].astype(np.int32)
 
     return H, y, int(d[pre + "iterations"]), cases()
+
+
+MULT_CIDS = (0, 5, 6, 8, 9, 10)
+
+
+def mult_case(cid):
+    """multiplication_tag vectors: msg, cw = msg*g, rx (codewords and arbitrary words), quot = rx / g."""
+    d = np.load(os.path.join(GOLDEN, "mult.npz"), allow_pickle=False)
+    pre = "c%d_" % cid
+    return d[pre + "msg"], d[pre + "cw"], d[pre + "rx"], d[pre + "quot"]

@@ -85,3 +85,26 @@ def test_full_size_roundtrip(cid, log2b):
     assert int((res["status"] != 0).sum()) == 0
     assert torch.equal(res["out"], cw)
     assert torch.equal(res["nerr"], nerr.to(torch.int32))
+
+
+@pytest.mark.parametrize("cid", G.MULT_CIDS)
+def test_multiplication_tag_golden(cid):
+    """multiplication_tag against the reference's committed outputs: encode c = a g, message extraction
+    a = b / g (extract_multiplication_kernel), also for words that are not codewords."""
+    msg, cw, rx, quot = G.mult_case(cid)
+    code = make_code(cid, coding="multiplication")
+    assert np.array_equal(code.encode_batch(msg), cw)
+    assert np.array_equal(code.extract_batch(rx), quot)
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t, coding=1)
+    rng = np.random.default_rng(cid)
+    hi = 2 if fam == BCH else 1 << q
+    big = rng.integers(0, hi, (5000, o.n)).astype(np.uint8)
+    assert np.array_equal(code.extract_batch(big), o.extract(big))
+    # decode = correct + extract with t errors on a * g
+    bad = cw.copy()
+    for f in range(len(bad)):
+        for p in rng.choice(o.n, t, replace=False):
+            bad[f, p] ^= 1 if fam == BCH else int(rng.integers(1, hi))
+    res = code.decode_batch(bad)
+    assert (res["status"] == 0).all() and np.array_equal(res["msg"], msg)

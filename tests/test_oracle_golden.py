@@ -114,3 +114,13 @@ def test_minsum_alt_golden(cid):
         ok = st == 0
         assert np.array_equal(b[ok], gb[ok]) and np.array_equal(it[ok], git[ok]), (v, rule)
         assert np.array_equal(L[ok], gL[ok]), (v, rule)
+
+
+@pytest.mark.parametrize("cid", G.MULT_CIDS)
+def test_multiplication_golden(cid):
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t, coding=1)
+    msg, cw, rx, quot = G.mult_case(cid)
+    assert np.array_equal(o.encode(msg), cw)
+    assert np.array_equal(o.extract(rx), quot)
+    assert np.array_equal(quot[: len(msg) // 2], msg[: len(msg) // 2])

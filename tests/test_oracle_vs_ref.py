@@ -313,3 +313,22 @@ def test_minsum_on_h_alt_matches_reference(ref_libs, cid, iters, ebno, frames):
             if rule == O1:
                 accepted += int(ok.sum())
     assert accepted > 0
+
+
+@pytest.mark.parametrize("cid", sorted(REF_CODES))
+def test_multiplication_tag_coding(ref_libs, cid):
+    """c = a g (cyclic.h:29-33) and a = b / g for codewords and arbitrary words (cyclic.h:42-46)."""
+    ref0, _ = ref_libs
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t, coding=1)
+    rng = np.random.default_rng(8000 + cid)
+    hi = 2 if fam == BCH else 1 << q
+    msg = rng.integers(0, hi, (40, o.l)).astype(np.uint8)
+    msg[0] = 0
+    msg[1, -2:] = 0
+    cw = ref0.encode_mult(cid, msg)
+    assert np.array_equal(o.encode(msg), cw)
+    assert np.array_equal(ref0.decode_mult(cid, cw), msg)
+    rx = rng.integers(0, hi, (40, o.n)).astype(np.uint8)
+    rx[0, -5:] = 0
+    assert np.array_equal(o.extract(np.concatenate([cw, rx])), ref0.decode_mult(cid, np.concatenate([cw, rx])))
