@@ -31,6 +31,11 @@
 namespace ccamd {
 namespace {
 
+#ifndef CC_ALG_BM_SHORTCUT
+#define CC_ALG_BM_SHORTCUT 1
+#endif
+constexpr bool kBmShortcut = CC_ALG_BM_SHORTCUT != 0;
+
 struct WaveScratch {
   uint8_t S[64];    // syndromes
   uint8_t lam[72];  // lambda coefficients
@@ -132,6 +137,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
       status = CC_FRAME_ERASURES;  // more erasures than 2t cannot be located (bch.h:105-107)
     } else if (any_syndrome != 0) {  // wave-uniform
       uint32_t lam;
+      int bm_len = -1;  // LFSR length L of Berlekamp-Massey (errors only), -1 otherwise
       const int rho = static_cast<int>(nerase);
       if (alg == CC_ALG_EUKLID) {
         // ---- Euklid / Sugiyama with erasures, hard_decision.h:157-196 (lane j <-> coefficient j) ----
@@ -180,6 +186,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
       }
       uint32_t bpoly = lam;
       int l = static_cast<int>(nerase);
+      bm_len = -2;  // set below
       for (int i = rho; i < t2; ++i) {
         bpoly = shift_up(bpoly);  // b = b * x
         const bool in_sum = lane >= 1 && lane <= l && lane <= i;
@@ -194,6 +201,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
           lam = tnew;
         }
       }
+      bm_len = l;
       }
       const unsigned long long nz = __ballot(lam != 0);
       const int deg = 63 - __builtin_clzll(nz | 1ull);
@@ -248,11 +256,20 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
       }
 
       // ---- verify: syndromes of the error pattern must equal the received syndromes (cyclic.h:243-248) ----
-      if (status == CC_FRAME_OK) {
+      // Without erasures the test is decided by BM's own bookkeeping: lambda generates S_1..S_2t as an LFSR of
+      // length L.  If L = deg lambda and lambda has L distinct roots X_i^-1 (checked above), the values Y_i that
+      // solve the first L syndrome equations (Forney; all ones for a binary word, since S_2j = S_j^2 forces
+      // Y_i^2 = Y_i and Y_i = 0 would contradict the minimality of L) reproduce all 2t syndromes, because both
+      // sequences obey the same recurrence from the same L initial values: the re-check cannot fail.  If
+      // L != deg lambda nothing is known and the syndromes of the error pattern are evaluated.
+      const bool verified_by_bm = kBmShortcut && rho == 0 && bm_len == deg;
+      if (status == CC_FRAME_OK)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) corr[c] = isroot[c] ? yv[c] : 0u;
+      if (status == CC_FRAME_OK && !verified_by_bm) {
         uint32_t ly[4], ev[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          corr[c] = isroot[c] ? yv[c] : 0u;
           ly[c] = lg[corr[c]];
           ev[c] = e0[c];
         }

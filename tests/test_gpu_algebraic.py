@@ -198,3 +198,27 @@ def test_api_errors_and_device_pointers():
         res = code.correct_batch(torch.from_numpy(rx).cuda())
     s.synchronize()
     assert (res["status"] == 0).all() and np.array_equal(res["out"].cpu().numpy(), cw)
+
+
+@pytest.mark.parametrize("cid,frames", [(0, 30000), (1, 20000), (4, 20000), (7, 20000), (8, 30000), (9, 20000),
+                                        (10, 600)])
+def test_recheck_decided_by_bm_length(cid, frames):
+    """The kernel skips the syndrome re-check (cyclic.h:243-248) when BM's LFSR length equals deg lambda and the
+    root count matched (proof in algebraic.hip); uniformly random words and heavy error patterns hit every
+    other case.  Status classes (root count vs re-check) must match the oracle frame for frame."""
+    o = Oracle(*REF_CODES[cid])
+    rng = np.random.default_rng(9000 + cid)
+    hi = 2 if o.family == BCH else 1 << o.q
+    cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+    rx = cw.copy()
+    third = frames // 3
+    rx[:third] = rng.integers(0, hi, (third, o.n))  # arbitrary words
+    for f in range(third, frames):
+        rx[f] = corrupt(rng, o, cw[f], int(rng.integers(o.t + 1, min(o.n, 3 * o.t + 3))))
+    for alg in (BM, PGZ):
+        res = make_code(cid, alg).correct_batch(rx)
+        check_against_oracle(res, o, alg, rx)
+    st = make_code(cid, BM).correct_batch(rx)["status"]
+    assert (st == 2).any() and ((st == 0).any() or cid == 10)
+    if cid in (8, 9):  # re-check failures exist for the small RS codes (never for a binary word, see the proof)
+        assert (st == 3).any()
