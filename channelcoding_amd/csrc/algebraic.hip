@@ -25,6 +25,8 @@
 //
 // Lane roles: in the syndrome / root-search / verify phases lane l owns the positions
 // p = l + 64c (c < 4); in the Berlekamp-Massey phase lane j owns coefficient j of lambda and b.
+#include <cstdlib>
+
 #include "cc_internal.hpp"
 #include "wave_ops.hpp"
 
@@ -63,6 +65,8 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   WaveScratch &W = scratch[wid];
+  const int dbg_stop = alg >> 8;  // timing experiments only (CC_AMD_ALG_STOP): 1 after syndromes, 2 after BM, 3 after roots
+  alg &= 0xFF;
   const int n = T->n, nroots = T->nroots, nn = n;  // full-length codes: n = 2^q - 1
   const int t2 = nroots;
   const bool is_rs = T->family == CC_FAMILY_RS;
@@ -135,7 +139,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
     uint32_t corr[4] = {0, 0, 0, 0};
     if (any_syndrome != 0 && nerase > static_cast<uint32_t>(t2)) {
       status = CC_FRAME_ERASURES;  // more erasures than 2t cannot be located (bch.h:105-107)
-    } else if (any_syndrome != 0) {  // wave-uniform
+    } else if (any_syndrome != 0 && dbg_stop != 1) {  // wave-uniform
       uint32_t lam;
       int bm_len = -1;  // LFSR length L of Berlekamp-Massey (errors only), -1 otherwise
       const int rho = static_cast<int>(nerase);
@@ -209,6 +213,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
       // the PGZ tag runs as bounded-distance decoding: locator degree within capability
       if (alg == CC_ALG_PGZ && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;
       if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
+      if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
 
       // ---- root search: position p is in error iff lambda(alpha^-p) = 0 ----
       uint32_t isroot[4] = {0, 0, 0, 0};
@@ -232,6 +237,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
         if (count != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
       }
 
+      if (dbg_stop == 3) status = CC_FRAME_LOCATOR;
       // ---- error values ----
       uint32_t yv[4] = {1, 1, 1, 1};  // bch.h:80-83
       if (status == CC_FRAME_OK && is_rs) {
@@ -398,15 +404,22 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
                      hipStream_t stream) {
   if (B == 0) return CC_OK;
+  if (algebraic_chunk_supported(code, d_er_off != nullptr))
+    return launch_algebraic_chunk(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
   const unsigned long long blocks_needed = (B + 3) / 4;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
+  static const int dbg_stop = [] {
+    const char *e = std::getenv("CC_AMD_ALG_STOP");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
   if (float_in)
-    hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_in,
+    hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg, d_in,
                        d_er, d_er_off, d_out, d_nerr, d_status, Bq);
   else
-    hipLaunchKernelGGL(algebraic_kernel<false>, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm,
+    hipLaunchKernelGGL(algebraic_kernel<false>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg,
                        d_in, d_er, d_er_off, d_out, d_nerr, d_status, Bq);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "algebraic kernel launch");

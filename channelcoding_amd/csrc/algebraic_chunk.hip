@@ -1,0 +1,464 @@
+// algebraic_chunk.hip -- the algebraic chain for Berlekamp-Massey / PGZ without erasures, restructured so
+// that each stage runs in the lane mapping that suits it.  A wavefront owns a chunk of FPW frames:
+//
+//   A  syndromes            one frame at a time, lane l owns positions l + 64c (parallel over positions);
+//                           S_j and log S_j go to LDS as [j][frame]
+//   B  Berlekamp-Massey     ONE LANE PER FRAME (hard_decision.h:116-155).  BM is a serial recurrence of 2t
+//                           steps; with a wavefront per frame every step pays a 6-stage cross-lane reduction for
+//                           the discrepancy plus dependent table look-ups for 17 useful lanes.  Here lambda, b and
+//                           the syndromes of frame f live in LDS column f ([coefficient][frame], conflict-free for
+//                           any row), polynomials are kept in the log domain with log 0 := 512 and an antilog
+//                           table that is zero above 510, so a GF multiply-accumulate is two linear LDS reads, one
+//                           table gather and an XOR, with no zero tests
+//   C  root search, error values, re-check, store: one frame at a time again (parallel over positions)
+//
+// Erasures and the Euklid tag stay on algebraic_kernel (algebraic.hip).  Same results as that kernel bit for
+// bit (tests/test_gpu_algebraic.py runs both through CC_AMD_NO_CHUNK=1).
+#include <cstdlib>
+
+#include "cc_internal.hpp"
+#include "wave_ops.hpp"
+
+namespace ccamd {
+namespace {
+
+constexpr uint32_t kLogZero = 512;  // log of 0: ex[kLogZero + anything < 512] = 0
+
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~lane63(wave_umin(~v)); }
+
+struct ChunkLayout {  // byte offsets inside one wavefront's LDS region
+  int SL, LL, BL, SV, LV, DEG, LEN, CSL, CLL, OML, CS, RP, VAL, bytes;
+};
+__host__ __device__ inline ChunkLayout chunk_layout(int t2, int fpw) {
+  ChunkLayout c;
+  const int nc = t2 + 1;
+  c.SL = 0;                      // u16 [t2][fpw]   log S_j
+  c.LL = c.SL + 2 * t2 * fpw;    // u16 [nc][fpw]   log lambda_m
+  c.BL = c.LL + 2 * nc * fpw;    // u16 [nc][fpw]   log b_m
+  c.SV = c.BL + 2 * nc * fpw;    // u8  [t2][fpw]   S_j
+  c.LV = c.SV + t2 * fpw;        // u8  [nc][fpw]   lambda_m
+  c.DEG = c.LV + nc * fpw;       // u8  [fpw]       deg lambda
+  c.LEN = c.DEG + fpw;           // u8  [fpw]       LFSR length L
+  // stage C scratch for the frame being corrected (contiguous copies of its column)
+  c.CSL = (c.LEN + fpw + 1) & ~1;  // u16 [64]   log S_j
+  c.CLL = c.CSL + 128;             // u16 [72]   log lambda_m
+  c.OML = c.CLL + 144;             // u16 [64]   log omega_j
+  c.CS = c.OML + 128;              // u8  [64]   S_j
+  c.RP = c.CS + 64;                // u8  [64]   positions of the located errors
+  c.VAL = c.RP + 64;               // u8  [64]   their values
+  c.bytes = (c.VAL + 64 + 15) & ~15;
+  return c;
+}
+
+template <bool FLOAT_IN, int FPW>
+__global__ void __launch_bounds__(256, 4)
+algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__restrict__ in_raw,
+                       uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
+                       unsigned long long B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *ex = smem;                                            // [1024]
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);     // [256]
+  uint8_t *lg = smem + 1536;                                     // [256] plain log table (log 0 = 0), stages A / C
+  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+
+  const int dbg_stop = alg >> 8;  // timing experiments only (CC_AMD_ALG_STOP): 1 after syndromes, 2 after BM, 3 after roots
+  alg &= 0xFF;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = T->n, nn = n, t2 = T->nroots, nc = t2 + 1;
+  const bool is_rs = T->family == CC_FAMILY_RS;
+  const ChunkLayout lay = chunk_layout(t2, FPW);
+  uint8_t *base = smem + 1792 + wid * lay.bytes;
+  uint16_t *SL = reinterpret_cast<uint16_t *>(base + lay.SL);
+  uint16_t *LL = reinterpret_cast<uint16_t *>(base + lay.LL);
+  uint16_t *BL = reinterpret_cast<uint16_t *>(base + lay.BL);
+  uint8_t *SV = base + lay.SV, *LV = base + lay.LV, *DEG = base + lay.DEG, *LEN = base + lay.LEN;
+  uint16_t *CSL = reinterpret_cast<uint16_t *>(base + lay.CSL);
+  uint16_t *CLL = reinterpret_cast<uint16_t *>(base + lay.CLL);
+  uint16_t *OML = reinterpret_cast<uint16_t *>(base + lay.OML);
+  uint8_t *CS = base + lay.CS, *RP = base + lay.RP, *VAL = base + lay.VAL;
+
+  // per-lane exponent bookkeeping (roots alpha^(r0 + j step)): position p = lane + 64 c
+  const int r0 = T->roots_log[0];
+  const int step = t2 > 1 ? (T->roots_log[1] + nn - r0) % nn : 0;
+  uint32_t e0[4], dstep[4], xinv[4];
+  bool valid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int p = lane + 64 * c;
+    valid[c] = p < n;
+    e0[c] = static_cast<uint32_t>((r0 * p) % nn);
+    dstep[c] = static_cast<uint32_t>((step * p) % nn);
+    xinv[c] = static_cast<uint32_t>((nn - (p % nn)) % nn);
+  }
+  uint32_t dk[4][4];  // (k + 1) * dstep mod nn, k = 0..3
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dk[c][k] = (static_cast<uint32_t>(k + 1) * dstep[c]) % static_cast<uint32_t>(nn);
+  auto load_symbols = [&](unsigned long long frame, uint32_t (&sym)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int p = lane + 64 * c;
+      if (FLOAT_IN)  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
+        sym[c] = valid[c] ? (static_cast<const float *>(in_raw)[frame * n + p] < 0.0f ? 1u : 0u) : 0u;
+      else
+        sym[c] = valid[c] ? (static_cast<const uint8_t *>(in_raw)[frame * n + p] & static_cast<uint32_t>(n)) : 0u;
+    }
+  };
+
+  const unsigned long long nchunks = (B + FPW - 1) / FPW;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * FPW;
+    const int frames = static_cast<int>((B - first) < static_cast<unsigned long long>(FPW) ? (B - first) : FPW);
+
+    // ---------------- A: syndromes (cyclic.h:53-63), four per DPP reduction ----------------
+    // Term of S_j at position p: b_p alpha^(root_j p) = ex[lt + k d] with lt = log b_p + r0 p (mod nn) advanced
+    // by 4 d per group of four syndromes, d = step * p (mod nn); the multiples k d (mod nn) are per-lane
+    // constants, so a term costs one add, one table read and one XOR.  A zero symbol parks lt on the zero
+    // part of the table (log 0 = 512) and advances by nn, which the wrap undoes.
+    unsigned long long smask = 0;  // frames with a non-zero syndrome
+    constexpr int PF = 3;          // frames in flight: the stage is latency-bound otherwise (255 B per frame)
+    uint32_t symq[PF][4];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) symq[k][c] = 0;
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < frames) load_symbols(first + k, symq[k]);
+    for (int s = 0; s < frames; ++s) {
+      {
+        uint32_t sym[4], lt[4], adv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t v = sym[c] = symq[0][c];
+          uint32_t l0 = lg[v] + e0[c];
+          l0 = umin32(l0, l0 - static_cast<uint32_t>(nn));
+          lt[c] = v ? l0 : kLogZero;
+          adv[c] = v ? dk[c][3] : static_cast<uint32_t>(nn);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < PF; ++k)  // rotate the queue, refill its tail
+#pragma unroll
+          for (int c = 0; c < 4; ++c) symq[k][c] = symq[k + 1][c];
+        if (s + PF < frames) load_symbols(first + s + PF, symq[PF - 1]);
+        uint32_t any = 0;
+        for (int j0 = 0; j0 < t2; j0 += 4) {
+          uint32_t t0 = 0, t1 = 0, t2v = 0, t3 = 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            t0 ^= ex[lt[c]];
+            t1 ^= ex[lt[c] + dk[c][0]];
+            t2v ^= ex[lt[c] + dk[c][1]];
+            t3 ^= ex[lt[c] + dk[c][2]];
+            lt[c] += adv[c];
+            lt[c] = umin32(lt[c], lt[c] - static_cast<uint32_t>(nn));
+          }
+          uint32_t packed = t0 | (t1 << 8) | (t2v << 16) | (t3 << 24);
+          packed = lane63(wave_xor(packed));
+          if (j0 + 4 > t2) packed &= 0xFFFFFFFFu >> (8 * (j0 + 4 - t2));  // t2 is not a multiple of four
+          any |= packed;
+          if (lane < 4 && j0 + lane < t2) {
+            const uint32_t v = (packed >> (8 * lane)) & 0xFFu;
+            SV[(j0 + lane) * FPW + s] = static_cast<uint8_t>(v);
+            SL[(j0 + lane) * FPW + s] = lg2[v];
+          }
+        }
+        if (any != 0 && dbg_stop != 1) {
+          smask |= 1ull << s;
+        } else {  // a codeword: done (cyclic.h:225-231)
+          const unsigned long long frame = first + s;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (valid[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c]);
+          if (lane == 0) {
+            if (nerr_out) nerr_out[frame] = 0;
+            if (status_out) status_out[frame] = CC_FRAME_OK;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- B: Berlekamp-Massey, one lane per frame (hard_decision.h:116-155) ----------------
+    if (smask != 0) {  // wave-uniform
+      const int f = lane & (FPW - 1);
+      const bool mine = lane < FPW && ((smask >> lane) & 1ull);
+      if (lane < FPW) {
+        for (int m = 0; m < nc; ++m) {  // lambda = b = 1
+          LV[m * FPW + f] = m == 0;
+          LL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
+          BL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
+        }
+      }
+      int l = 0, shift = 0;  // b is stored unshifted; b(x) x^shift is the polynomial of the recurrence
+      for (int i = 0; i < t2; ++i) {
+        shift += 1;  // b = b * x, :134
+        const int lw = static_cast<int>(wave_umax(mine ? static_cast<uint32_t>(l) : 0u));
+        // discrepancy :139-141; lambda_m = 0 (log 512) beyond its degree, so no per-lane bound is needed
+        uint32_t d = SV[i * FPW + f];
+        const int mm = i < lw ? i : lw;
+        for (int m = 1; m <= mm; ++m) d ^= ex[LL[m * FPW + f] + SL[(i - m) * FPW + f]];
+        const bool upd = mine && d != 0;
+        const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
+        const uint32_t ld = lg2[d];
+        const uint32_t linv = static_cast<uint32_t>(nn) - ld;  // log of d^-1 (or nn for d = 1: wrapped below)
+        const int lnew = grow ? i + 1 - l : l;
+        const int cap = static_cast<int>(wave_umax(upd ? static_cast<uint32_t>(lnew) : 0u));
+        if (__any(upd)) {
+          // lambda += d * b * x^shift, and where the register grows b := lambda_old / d; descending m so that the
+          // shifted reads of the old b (index m - shift < m) happen before that index is overwritten
+          for (int m = cap; m >= 0; --m) {
+            const uint32_t lold = LL[m * FPW + f];
+            const uint32_t lv = LV[m * FPW + f];
+            const int bi = m - shift;
+            const uint32_t bt = bi >= 0 ? BL[(bi >= 0 ? bi : 0) * FPW + f] : kLogZero;
+            const uint32_t nv = lv ^ ex[ld + bt];
+            if (upd) {
+              LV[m * FPW + f] = static_cast<uint8_t>(nv);
+              LL[m * FPW + f] = lg2[nv];
+            }
+            if (grow) {
+              uint32_t q = lold + linv;
+              q = q >= static_cast<uint32_t>(nn) ? q - nn : q;
+              BL[m * FPW + f] = static_cast<uint16_t>(lold >= kLogZero ? kLogZero : q);
+            }
+          }
+        }
+        if (grow) {
+          l = lnew;
+          shift = 0;
+        }
+      }
+      if (mine) {
+        int deg = 0;
+        for (int m = t2; m >= 1; --m)
+          if (deg == 0 && LV[m * FPW + f] != 0) deg = m;
+        DEG[f] = static_cast<uint8_t>(deg);
+        LEN[f] = static_cast<uint8_t>(l);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- C: roots, error values, re-check, store ----------------
+    // All polynomial arithmetic on logs with log 0 = 512 (no zero tests): a term lambda_m X^-m is
+    // ex[log lambda_m + (m * log X^-1 mod nn)], the exponent advancing by one add + one wrap per coefficient.
+    // only frames with a non-zero syndrome are visited (the others were stored in stage A); two in flight
+    auto pop = [](unsigned long long &m) {
+      const int i = m ? __builtin_ctzll(m) : -1;
+      m &= m - 1;
+      return i;
+    };
+    unsigned long long todo = smask;
+    int s0 = pop(todo), s1 = pop(todo);
+    uint32_t q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
+    if (s0 >= 0) load_symbols(first + s0, q0);
+    if (s1 >= 0) load_symbols(first + s1, q1);
+    while (s0 >= 0) {
+      const int s = s0;
+      const unsigned long long frame = first + s;
+      uint32_t sym[4], corr[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sym[c] = q0[c];
+        q0[c] = q1[c];
+      }
+      s0 = s1;
+      s1 = pop(todo);
+      if (s1 >= 0) load_symbols(first + s1, q1);
+      int status = CC_FRAME_OK, nerr = 0;
+      {
+        const int deg = DEG[s], len = LEN[s];
+        // column s of the chunk arrays -> contiguous scratch (the strided reads conflict, do them once)
+        if (lane < t2) {
+          CS[lane] = SV[lane * FPW + s];
+          CSL[lane] = SL[lane * FPW + s];
+        }
+        for (int m = lane; m < nc; m += 64) CLL[m] = LL[m * FPW + s];
+        // the PGZ tag runs as bounded-distance decoding: locator degree within capability
+        if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+        if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
+        if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
+
+        // root search: position p is in error iff lambda(alpha^-p) = 0  (cyclic.h:126-150)
+        uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
+        if (status == CC_FRAME_OK) {
+          uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
+          for (int m = 0; m <= deg; ++m) {
+            const uint32_t lm = CLL[m];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              acc[c] ^= ex[lm + e[c]];
+              e[c] += xinv[c];
+              e[c] = umin32(e[c], e[c] - static_cast<uint32_t>(nn));
+            }
+          }
+          uint32_t count = 0;
+          const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            isroot[c] = (valid[c] && acc[c] == 0) ? 1u : 0u;
+            const unsigned long long mk = __ballot(isroot[c] != 0);
+            rank[c] = count + static_cast<uint32_t>(__builtin_popcountll(mk & below));
+            count += static_cast<uint32_t>(__builtin_popcountll(mk));
+          }
+          nerr = static_cast<int>(count);
+          if (nerr != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
+        }
+        if (dbg_stop == 3) status = CC_FRAME_LOCATOR;
+
+        // error values: bch.h:80-83 (all ones) / Forney for rs.h:41-78, one lane per located error
+        if (status == CC_FRAME_OK && is_rs) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (isroot[c]) RP[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
+          uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg
+          for (int m = 0; m <= deg; ++m) {
+            const uint32_t lm = CLL[m];
+            const bool in = lane >= m && lane < deg && lane - m < t2;
+            om ^= in ? ex[lm + CSL[in ? lane - m : 0]] : 0u;
+          }
+          OML[lane] = lg2[om];
+          uint32_t y = 0;
+          if (lane < deg) {
+            const uint32_t p = RP[lane];
+            const uint32_t xi = p ? static_cast<uint32_t>(nn) - p : 0u;  // log X^-1
+            uint32_t x2 = 2 * xi;
+            x2 = umin32(x2, x2 - static_cast<uint32_t>(nn));
+            uint32_t num = 0, den = 0, e = 0;
+            for (int j = 0; j < deg; ++j) {  // omega(X^-1)
+              num ^= ex[OML[j] + e];
+              e += xi;
+              e = umin32(e, e - static_cast<uint32_t>(nn));
+            }
+            e = 0;
+            for (int m = 1; m <= deg; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+              den ^= ex[CLL[m] + e];
+              e += x2;
+              e = umin32(e, e - static_cast<uint32_t>(nn));
+            }
+            y = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
+          }
+          VAL[lane] = static_cast<uint8_t>(y);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) corr[c] = isroot[c] ? VAL[rank[c]] : 0u;
+        } else if (status == CC_FRAME_OK) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) corr[c] = isroot[c];
+        }
+        // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip), evaluated otherwise
+        if (status == CC_FRAME_OK && len != deg) {
+          uint32_t ly[4], ev[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            ly[c] = lg[corr[c]];
+            ev[c] = e0[c];
+          }
+          uint32_t mismatch = 0;
+          for (int j0 = 0; j0 < t2; j0 += 4) {
+            uint32_t packed = 0, want = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              uint32_t term = 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                term ^= corr[c] ? ex[ly[c] + ev[c]] : 0u;
+                ev[c] += dstep[c];
+                ev[c] = ev[c] >= static_cast<uint32_t>(nn) ? ev[c] - nn : ev[c];
+              }
+              if (j0 + jj < t2) {
+                packed |= term << (8 * jj);
+                want |= static_cast<uint32_t>(CS[j0 + jj]) << (8 * jj);
+              }
+            }
+            mismatch |= lane63(wave_xor(packed)) ^ want;
+          }
+          if (mismatch != 0) status = CC_FRAME_RECHECK;
+        }
+      }
+      const bool ok = status == CC_FRAME_OK;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (valid[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
+      if (lane == 0) {
+        if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
+        if (status_out) status_out[frame] = status;
+      }
+      __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next frame
+    }
+  }
+}
+
+}  // namespace
+
+bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
+  static const bool disabled = [] {
+    const char *e = std::getenv("CC_AMD_NO_CHUNK");
+    return e && e[0] == '1';
+  }();
+  if (disabled || erasures) return false;
+  // measured (profiles/tools/rs_bench.py): with few syndromes the per-frame work is dominated by the frame's
+  // load/store latency and the one-wavefront-per-frame kernel with its higher occupancy wins
+  // (BCH(255,231), 6 syndromes: 1128 vs 899 M frames/s); with 32 syndromes this kernel wins (309 vs 220)
+  if (code->tab.roots.size() < 8) return false;
+  return code->desc.algorithm == CC_ALG_BM || code->desc.algorithm == CC_ALG_PGZ;
+}
+
+template <int FPW>
+static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
+                            int32_t *d_status, size_t B, hipStream_t stream) {
+  const int t2 = static_cast<int>(code->tab.roots.size());
+  const size_t lds = 1792 + 4 * static_cast<size_t>(chunk_layout(t2, FPW).bytes);
+  const unsigned long long chunks = (B + FPW - 1) / FPW;
+  const unsigned long long blocks_needed = (chunks + 3) / 4;
+  unsigned long long per_cu = (160 * 1024) / lds;
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
+  const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
+  const unsigned long long Bq = B;
+  static const int dbg_stop = [] {
+    const char *e = std::getenv("CC_AMD_ALG_STOP");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
+  hipError_t e = hipSuccess;
+  if (float_in) {
+    if (lds > 48 * 1024)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&algebraic_chunk_kernel<true, FPW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((algebraic_chunk_kernel<true, FPW>), dim3(grid), dim3(256), lds, stream, code->d_alg,
+                         alg_arg, d_in, d_out, d_nerr, d_status, Bq);
+  } else {
+    if (lds > 48 * 1024)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&algebraic_chunk_kernel<false, FPW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((algebraic_chunk_kernel<false, FPW>), dim3(grid), dim3(256), lds, stream, code->d_alg,
+                         alg_arg, d_in, d_out, d_nerr, d_status, Bq);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "algebraic chunk kernel launch");
+  return CC_OK;
+}
+
+int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
+                           int32_t *d_status, size_t B, hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  static const int fpw = [] {
+    const char *e = std::getenv("CC_AMD_CHUNK_FPW");
+    return e ? std::atoi(e) : 32;
+  }();
+  if (fpw == 16) return launch_chunk_fpw<16>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
+  if (fpw == 64) return launch_chunk_fpw<64>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
+  return launch_chunk_fpw<32>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
+}
+
+}  // namespace ccamd

@@ -621,9 +621,14 @@ int cc_awgn_llr_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
                    uint32_t *threads_per_workgroup, uint32_t *lds_bytes) {
   if (!code) return CC_ERR_INVALID_ARGUMENT;
-  std::string nm = "algebraic";
-  uint32_t f = 0, t = 0, l = 0;
-  if (code->soft) minsum_kernel_info(code, nm, f, t, l);
+  std::string nm = "algebraic_kernel";
+  uint32_t f = 4, t = 256, l = 1024;
+  if (code->soft) {
+    minsum_kernel_info(code, nm, f, t, l);
+  } else if (algebraic_chunk_supported(code, false)) {
+    nm = "algebraic_chunk_kernel<FPW=32> (algebraic_kernel with erasures)";
+    f = 128;
+  }
   if (name && cap) std::snprintf(name, cap, "%s", nm.c_str());
   if (frames_per_workgroup) *frames_per_workgroup = f;
   if (threads_per_workgroup) *threads_per_workgroup = t;

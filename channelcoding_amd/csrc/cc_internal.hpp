@@ -105,6 +105,10 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
 int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
                      hipStream_t stream);
+// algebraic_chunk.hip: BM / PGZ without erasures, Berlekamp-Massey with one lane per frame
+bool algebraic_chunk_supported(const cc_code *code, bool erasures);
+int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
+                           int32_t *d_status, size_t B, hipStream_t stream);
 int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,
                         uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
 // encode.hip

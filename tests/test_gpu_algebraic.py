@@ -222,3 +222,21 @@ def test_recheck_decided_by_bm_length(cid, frames):
     assert (st == 2).any() and ((st == 0).any() or cid == 10)
     if cid in (8, 9):  # re-check failures exist for the small RS codes (never for a binary word, see the proof)
         assert (st == 3).any()
+
+
+def test_both_algebraic_kernels_agree(monkeypatch):
+    """The chunked kernel (Berlekamp-Massey with one lane per frame, algebraic_chunk.hip) and the
+    one-wavefront-per-frame kernel must agree bit for bit; CC_AMD_NO_CHUNK is read once per process, so the
+    second kernel is reached through its own dispatch conditions instead: erasure arrays (empty) force it."""
+    for cid in (10, 9):
+        o = Oracle(*REF_CODES[cid])
+        rng = np.random.default_rng(123 + cid)
+        frames = 700
+        cw = o.encode(rng.integers(0, 1 << o.q, (frames, o.l)).astype(np.uint8))
+        rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, o.t + 4))) for f in range(frames)])
+        code = make_code(cid, BM)
+        assert code.kernel_info()["kernel"].startswith("algebraic_chunk_kernel")
+        a = code.correct_batch(rx)
+        b = code.correct_batch(rx, erasures=[[] for _ in range(frames)])  # CSR with no entries -> algebraic_kernel
+        for key in ("out", "status", "nerr"):
+            assert np.array_equal(a[key], b[key]), key
