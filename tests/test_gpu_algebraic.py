@@ -228,13 +228,14 @@ def test_both_algebraic_kernels_agree(monkeypatch):
     """The chunked kernel (Berlekamp-Massey with one lane per frame, algebraic_chunk.hip) and the
     one-wavefront-per-frame kernel must agree bit for bit; CC_AMD_NO_CHUNK is read once per process, so the
     second kernel is reached through its own dispatch conditions instead: erasure arrays (empty) force it."""
-    for cid in (10, 9):
-        o = Oracle(*REF_CODES[cid])
-        rng = np.random.default_rng(123 + cid)
+    for fam, q, t in ((RS, 8, 16), (RS, 6, 5), (BCH, 7, 4)):
+        o = Oracle(fam, q, t)
+        rng = np.random.default_rng(123 + q)
         frames = 700
-        cw = o.encode(rng.integers(0, 1 << o.q, (frames, o.l)).astype(np.uint8))
+        hi = 2 if fam == BCH else 1 << q
+        cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
         rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, o.t + 4))) for f in range(frames)])
-        code = make_code(cid, BM)
+        code = (cc.primitive_bch if fam == BCH else cc.rs)(q, cc.errors(t), cc.berlekamp_massey_tag())
         assert code.kernel_info()["kernel"].startswith("algebraic_chunk_kernel")
         a = code.correct_batch(rx)
         b = code.correct_batch(rx, erasures=[[] for _ in range(frames)])  # CSR with no entries -> algebraic_kernel

@@ -67,3 +67,26 @@ def test_bitflip_log_format(tmp_path):
     bitflip_simulation(code, 2, log_dir=str(tmp_path))()
     lines = (tmp_path / "(31, 16, 7)-BM.log").read_text().splitlines()
     assert lines[0] == "%7s %21s" % ("errors", "wer") and lines[1].startswith("      0 0.0")
+
+
+def test_benchmark_cli_bitflip_and_awgn(tmp_path):
+    """python -m channelcoding_amd.benchmark with the options of src/simulation/benchmark.c++:312-372."""
+    from channelcoding_amd import benchmark
+    rc = benchmark.main(["--simulation", "bitflip", "--algorithm", "MS", "--algorithm", "bm", "--k", "5", "--dmin", "7",
+                         "--errors", "3", "--stop-rule", "1", "--log-dir", str(tmp_path)])
+    assert rc == 0
+    ms = (tmp_path / "(31, 16, 7)-MS.log").read_text().splitlines()
+    assert ms[0] == "%7s %21s" % ("errors", "wer")
+    assert [float(l.split()[1]) for l in ms[1:]] == pytest.approx([0, 0, 138 / 465, 3557 / 4495], abs=1e-12)
+    bm = (tmp_path / "(31, 16, 7)-BM.log").read_text().splitlines()
+    assert [float(l.split()[1]) for l in bm[1:]] == [0, 0, 0, 0]
+    rc = benchmark.main(["-simulation", "awgn", "-algorithm", "nms", "-k", "6", "-dmin", "7", "-seed", "3",
+                         "--max-samples", "20000", "--log-dir", str(tmp_path)])
+    assert rc == 0
+    rows = (tmp_path / "(63, 45, 7)-NMS.log").read_text().splitlines()
+    wer = [float(l.split()[1]) for l in rows[1:]]
+    assert rows[0] == "%7s %21s" % ("ebno", "wer") and len(wer) >= 8
+    assert wer[0] > 0.1 and wer[-1] < 1e-3 and all(a >= b - 0.02 for a, b in zip(wer, wer[1:]))
+    with pytest.raises(RuntimeError):  # "File ... already exists." simulation.c++:72-81
+        benchmark.main(["--simulation", "bitflip", "--algorithm", "bm", "--k", "5", "--dmin", "7",
+                        "--log-dir", str(tmp_path)])

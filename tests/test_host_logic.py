@@ -137,3 +137,26 @@ def test_min_sum_decoder_host_logic():
         cc.min_sum_decoder(H, cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE)
     with pytest.raises(capi.CcError):
         cc.min_sum_decoder(H * 3, device=capi.DEVICE_NONE)
+
+
+def test_benchmark_cli_selection():
+    """Decoder registry and option semantics of src/simulation/benchmark.c++ (no GPU needed)."""
+    from channelcoding_amd import benchmark
+    reg = benchmark.registry()
+    assert len(reg) == 108  # 9 algorithms x k in 5..7 x dmin in 3,5,7,9 (benchmark.c++:23-166)
+    for name, k, d, shown in reg[::7]:
+        code = benchmark.build(name, k, d, capi.STOP_PARITY, device=capi.DEVICE_NONE)
+        text = code.to_string()
+        assert text.rsplit("-", 1)[1].lower() == name  # the key the reference derives from to_string(), :212-216
+        assert text.startswith("(%d, " % ((1 << k) - 1)) and shown == code.dmin >= d
+    # --dmin selects on the distance PRINTED by to_string(): primitive_bch<5, dmin<9>> is "(31, 11, 11)"
+    assert benchmark.reported_distances() == sorted({r[3] for r in reg}) and 11 in benchmark.reported_distances()
+    assert len(benchmark.select(None, None, None)) == 108
+    assert benchmark.select(["BM"], ["5"], ["all"]) == [("bm", 5, d) for d in (3, 5, 7, 9)]
+    assert benchmark.select(["ms", "nms"], ["5"], ["11"]) == [("ms", 5, 9), ("nms", 5, 9)]
+    assert benchmark.select(["ms"], ["5"], ["9"]) == []
+    with pytest.raises(SystemExit):
+        benchmark.select(["viterbi"], None, None)
+    with pytest.raises(SystemExit):
+        benchmark.select(None, ["8"], None)
+    assert benchmark.main(["--simulation", "fading"]) == 1 and benchmark.main(["--bogus"]) == 1
