@@ -28,8 +28,10 @@ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    // one v_mad_u64_u32 per product instead of a mul_lo / mul_hi pair (both quarter rate)
+    const uint64_t p0 = static_cast<uint64_t>(M0) * c0, p1 = static_cast<uint64_t>(M1) * c2;
+    const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+    const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
     const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0;
     c1 = n1;
@@ -41,57 +43,68 @@ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
   return Philox{{c0, c1, c2, c3}};
 }
 
+// Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 take their
+// argument in turns, so no range reduction is needed for u2 in [0, 1).
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1) {
   const float u1 = (static_cast<float>(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
   const float u2 = static_cast<float>(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
-  const float r = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincosf(6.28318530717958647692f * u2, &s, &c);
-  z0 = r * c;
-  z1 = r * s;
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
+// Message bit j of frame f is bit (j & 127) of Philox counter (f, j >> 7, 1).  G = lanes per frame (power of two
+// >= ceil(l / 16)); a lane expands 16 bits to bytes (eight lanes share one Philox block and each evaluates it:
+// cheaper than the byte-by-byte loop of one lane per block, which serialised 128 stores).
 __global__ void __launch_bounds__(256)
-random_bits_kernel(uint8_t *__restrict__ msg, int l, unsigned long long first_frame, unsigned long long frames,
-                   uint32_t k0, uint32_t k1) {
-  const int quads = (l + 127) / 128;  // one Philox call yields 128 bits
-  const unsigned long long total = frames * quads;
-  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
-  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-       idx += stride) {
-    const unsigned long long f = idx / quads;
-    const int qd = static_cast<int>(idx - f * quads);
+random_bits_kernel(uint8_t *__restrict__ msg, int l, int group_log2, unsigned long long first_frame,
+                   unsigned long long frames, uint32_t k0, uint32_t k1) {
+  const int G = 1 << group_log2;
+  const unsigned long long tid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (static_cast<unsigned long long>(gridDim.x) * blockDim.x) >> group_log2;
+  const int q = static_cast<int>(tid & static_cast<unsigned long long>(G - 1));
+  if (16 * q >= l) return;
+  for (unsigned long long f = tid >> group_log2; f < frames; f += stride) {
     const unsigned long long gf = first_frame + f;
-    const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), qd, 1u, k0, k1);
-    for (int b = 0; b < 128; ++b) {
-      const int j = qd * 128 + b;
-      if (j < l) msg[f * l + j] = (p.c[b >> 5] >> (b & 31)) & 1u;
-    }
+    const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), q >> 3, 1u, k0, k1);
+    const int w = (q & 7) >> 1;
+    const uint32_t word = w == 0 ? p.c[0] : w == 1 ? p.c[1] : w == 2 ? p.c[2] : p.c[3];
+    const uint32_t bits = (word >> (16 * (q & 1))) & 0xFFFFu;
+    uint8_t *dst = msg + f * l + 16 * q;
+    const int count = l - 16 * q < 16 ? l - 16 * q : 16;
+    for (int b = 0; b < count; ++b) dst[b] = (bits >> b) & 1u;
   }
 }
 
+// G = lanes per frame (power of two >= ceil(n / 4)), lane q of a group draws the four values 4q .. 4q + 3 of its
+// frame from Philox counter (frame, q): no division by n anywhere, 16-byte stores except for a ragged tail.
 __global__ void __launch_bounds__(256)
-awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, unsigned long long first_frame,
-            unsigned long long frames, float sigma, uint32_t k0, uint32_t k1) {
-  const int quads = (n + 3) / 4;
-  const unsigned long long total = frames * quads;
-  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
-  for (unsigned long long idx = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-       idx += stride) {
-    const unsigned long long f = idx / quads;
-    const int qd = static_cast<int>(idx - f * quads);
+awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, int group_log2,
+            unsigned long long first_frame, unsigned long long frames, float sigma, uint32_t k0, uint32_t k1) {
+  const int G = 1 << group_log2;
+  const unsigned long long tid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (static_cast<unsigned long long>(gridDim.x) * blockDim.x) >> group_log2;
+  const int qd = static_cast<int>(tid & static_cast<unsigned long long>(G - 1));
+  if (4 * qd >= n) return;
+  for (unsigned long long f = tid >> group_log2; f < frames; f += stride) {
     const unsigned long long gf = first_frame + f;
     const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), qd, 0u, k0, k1);
     float z[4];
     box_muller(p.c[0], p.c[1], z[0], z[1]);
     box_muller(p.c[2], p.c[3], z[2], z[3]);
+    float *dst = llr + f * n + 4 * qd;
+    const uint8_t *src = sent ? sent + f * n + 4 * qd : nullptr;
+    if (4 * qd + 4 <= n) {
+      float x[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int j = 4 * qd + s;
-      if (j < n) {
-        const float x = (sent != nullptr && sent[f * n + j]) ? -1.0f : 1.0f;  // BPSK 0 -> +1
-        llr[f * n + j] = x + sigma * z[s];
-      }
+      for (int s = 0; s < 4; ++s) x[s] = ((src && src[s]) ? -1.0f : 1.0f) + sigma * z[s];  // BPSK 0 -> +1
+      // frames are n floats apart, so dst is 4-byte aligned only: four dword stores the compiler may merge
+      dst[0] = x[0];
+      dst[1] = x[1];
+      dst[2] = x[2];
+      dst[3] = x[3];
+    } else {
+      for (int s = 0; 4 * qd + s < n; ++s) dst[s] = ((src && src[s]) ? -1.0f : 1.0f) + sigma * z[s];
     }
   }
 }
@@ -199,17 +212,22 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
   const uint8_t *sent = nullptr;
   if (random_codewords) {
     if (!d_sent || !d_msg_scratch) return CC_ERR_INVALID_ARGUMENT;
-    const unsigned long long items = static_cast<unsigned long long>(frames) * ((l + 127) / 128);
+    int bits_log2 = 0;
+    while ((16 << bits_log2) < l) ++bits_log2;
+    const unsigned long long items = static_cast<unsigned long long>(frames) << bits_log2;
     hipLaunchKernelGGL(random_bits_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_msg_scratch, l,
-                       static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), k0, k1);
+                       bits_log2, static_cast<unsigned long long>(first_frame),
+                       static_cast<unsigned long long>(frames), k0, k1);
     const int rc = launch_encode(code, d_msg_scratch, d_sent, frames, stream);
     if (rc != CC_OK) return rc;
     sent = d_sent;
   } else if (d_sent) {
     CC_HIP_TRY(hipMemsetAsync(d_sent, 0, frames * static_cast<size_t>(n), stream));
   }
-  const unsigned long long items = static_cast<unsigned long long>(frames) * ((n + 3) / 4);
-  hipLaunchKernelGGL(awgn_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n,
+  int group_log2 = 0;
+  while ((4 << group_log2) < n) ++group_log2;
+  const unsigned long long items = static_cast<unsigned long long>(frames) << group_log2;
+  hipLaunchKernelGGL(awgn_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n, group_log2,
                      static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
                      k1);
   hipError_t e = hipGetLastError();
@@ -220,7 +238,7 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
 int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,
            uint64_t *d_counters, hipStream_t stream) {
   if (frames == 0) return CC_OK;
-  const size_t chunk_max = size_t(1) << 16;
+  const size_t chunk_max = size_t(1) << 20;  // ~1.6 GB of workspace for n = 255: long launches, short tails
   const size_t chunk = frames < chunk_max ? frames : chunk_max;
   if (!code->mc) code->mc = new McWorkspace();
   std::lock_guard<std::mutex> guard(code->mc->lock);
@@ -254,7 +272,7 @@ int mc_awgn(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, 
             float *d_llr, uint8_t *d_sent, hipStream_t stream) {
   if (frames == 0) return CC_OK;
   if (!random_codewords) return launch_awgn(code, ebno_db, seed, first_frame, frames, 0, d_llr, d_sent, nullptr, stream);
-  const size_t chunk_max = size_t(1) << 16;
+  const size_t chunk_max = size_t(1) << 20;  // ~1.6 GB of workspace for n = 255: long launches, short tails
   const size_t chunk = frames < chunk_max ? frames : chunk_max;
   if (!code->mc) code->mc = new McWorkspace();
   std::lock_guard<std::mutex> guard(code->mc->lock);
