@@ -29,6 +29,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 measured attainable
 
+# The bound that actually holds: VALU issue.  Instruction mix of one iteration of the four
+# resident frames of a wavefront, counted in the ISA of minsum_diag_kernel<K=24,D=7> (hipcc -S, loop body):
+# 2158 VALU of which 520 are f32 add/sub; issue cost per wave instruction measured on MI355X
+# (profiles/r01_ubench_instruction_rates.txt): 2.5 cycles for f32 add/sub/mul, 4.3 for every other VALU op.
+DIAG_VALU_PER_WAVE_ITER = {"f32_add_sub_mul": 520, "other": 1638, "lds": 574}
+ISSUE_CYCLES = {"f32_add_sub_mul": 2.5, "other": 4.3}
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
+
 
 def measured_traffic(kernel, batch_log2):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
@@ -301,6 +309,15 @@ def main():
                         % mean_iters,
             },
         }
+        if name.value.decode().startswith("minsum_diag_kernel"):
+            cyc = sum(DIAG_VALU_PER_WAVE_ITER[k] * ISSUE_CYCLES[k] for k in ISSUE_CYCLES) / 4.0  # per frame-iteration
+            frame_iters = B * mean_iters / (kernel_ms * 1e-3)
+            out["roofline"]["valu_issue"] = {
+                "simd_cycles_per_frame_iteration": cyc, "frame_iterations_per_s": frame_iters,
+                "achieved_simd_cycles_per_s": frame_iters * cyc, "peak_simd_cycles_per_s": SIMDS * CLOCK_HZ,
+                "frac": frame_iters * cyc / (SIMDS * CLOCK_HZ),
+                "note": "fraction of all SIMD issue cycles spent issuing this kernel's VALU instructions",
+            }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(y[:4096].cpu().numpy(), args.iterations)
         else:

@@ -264,3 +264,20 @@ def test_minsum_long_low_rate_codes(q, t, ov, iters):
     ob, oL, oit, ost = o.minsum(ov, iters, y[sub], alpha, beta, O2, fast=True)
     check({k: v[sub] for k, v in res.items()}, ob, oL, oit, ost, (q, t))
     assert (res["status"] == 0).any() and (res["status"] != 0).any()  # both outcomes exercised
+
+
+def test_host_buffers_match_device_buffers():
+    """cc_correct_soft_batch (host pointers) and cc_correct_soft_batch_dev (device pointers) on the same large
+    batch: identical results."""
+    import torch
+    code = cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(10))
+    B = (1 << 17) + 777
+    rng = np.random.default_rng(2024)
+    y = (1.0 + code.sigma(4.0) * rng.standard_normal((B, code.n), dtype=np.float32)).astype(np.float32)
+    host = code.correct_batch(y, want_L=True)
+    dev = code.correct_batch(torch.from_numpy(y).cuda(), want_L=True)
+    assert np.array_equal(host["out"], dev["out"].cpu().numpy())
+    assert np.array_equal(host["L"], dev["L"].cpu().numpy())
+    assert np.array_equal(host["iters"].astype(np.int64), dev["iters"].cpu().numpy().astype(np.int64) & 0xFFFF)
+    assert np.array_equal(host["status"], dev["status"].cpu().numpy())
+    assert 0.2 < (host["status"] == 0).mean() < 0.95
