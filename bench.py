@@ -31,9 +31,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 measured attai
 
 # The bound that actually holds: VALU issue.  Instruction mix of one iteration of the four
 # resident frames of a wavefront, counted in the ISA of minsum_diag_kernel<K=24,D=7> (hipcc -S, loop body):
-# 2158 VALU of which 520 are f32 add/sub; issue cost per wave instruction measured on MI355X
+# 2062 VALU of which 520 are f32 add/sub; issue cost per wave instruction measured on MI355X
 # (profiles/r01_ubench_instruction_rates.txt): 2.5 cycles for f32 add/sub/mul, 4.3 for every other VALU op.
-DIAG_VALU_PER_WAVE_ITER = {"f32_add_sub_mul": 520, "other": 1638, "lds": 574}
+DIAG_VALU_PER_WAVE_ITER = {"f32_add_sub_mul": 520, "other": 1542, "lds": 574}
 ISSUE_CYCLES = {"f32_add_sub_mul": 2.5, "other": 4.3}
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 

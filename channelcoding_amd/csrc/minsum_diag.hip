@@ -66,9 +66,9 @@ __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > 
 // one butterfly stage of the (min1, min2-with-multiplicity) all-reduce inside a 16-lane row
 template <int CTRL>
 __device__ __forceinline__ void pair_stage(uint32_t &m1, uint32_t &m2) {
-  // all four patterns used here (quad_perm, row_half_mirror, row_mirror) read a valid lane everywhere,
-  // so `old` is never selected: pass the value itself instead of an identity that would cost a v_mov
-  const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(m2), static_cast<int>(m2), CTRL, 0xF, 0xF, false));
+  // all four patterns used here (quad_perm, row_half_mirror, row_mirror) read a valid lane everywhere, so the
+  // `old` operand is never selected: mov_dpp leaves it undefined, update_dpp(m2, m2) would cost a v_mov to tie it
+  const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m2), CTRL, 0xF, 0xF, true));
   const uint32_t lo = umin32(m1, dpp16<CTRL, 0xFFFFFFFFu>(m1));
   const uint32_t hi = umax32(m1, dpp16<CTRL, 0u>(m1));
   m1 = lo;
