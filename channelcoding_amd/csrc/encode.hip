@@ -22,15 +22,15 @@ encode_division_kernel(const AlgebraicTables *__restrict__ T, const uint8_t *__r
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t *ex = smem;             // 512
   uint8_t *lg = smem + 512;       // 256
-  uint8_t *par = smem + 768;      // 4 waves x 128 parity bytes
-  uint8_t *pt = smem + 768 + 512;  // k * l
+  uint8_t *par = smem + 768;       // 4 waves x 256 parity bytes (k <= 254)
+  uint8_t *pt = smem + 768 + 1024;  // k * l
   const int n = T->n, k = T->k, l = T->l;
   for (int i = threadIdx.x; i < 512; i += 256) ex[i] = T->exp[i];
   lg[threadIdx.x] = T->log[threadIdx.x];
   for (int i = threadIdx.x; i < k * l; i += 256) pt[i] = PT[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint8_t *mypar = par + wid * 128;
+  uint8_t *mypar = par + wid * 256;
   const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
   const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
   for (unsigned long long f = wave; f < B; f += nwaves) {
@@ -199,7 +199,7 @@ int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size
   if (code->desc.coding == CC_CODING_MULTIPLICATION) {
     hipLaunchKernelGGL(encode_multiplication_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, d_msg, d_cw, Bq);
   } else {
-    const size_t lds = 768 + 512 + static_cast<size_t>(code->tab.k) * code->tab.l;
+    const size_t lds = 768 + 1024 + static_cast<size_t>(code->tab.k) * code->tab.l;
     if (lds > 64 * 1024) {
       set_last_error("encoder parity table does not fit 64 KiB of LDS for this code");
       return CC_ERR_UNSUPPORTED;

@@ -241,3 +241,25 @@ def test_both_algebraic_kernels_agree(monkeypatch):
         b = code.correct_batch(rx, erasures=[[] for _ in range(frames)])  # CSR with no entries -> algebraic_kernel
         for key in ("out", "status", "nerr"):
             assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("fam,q,t,frames", [(BCH, 3, 1, 500), (BCH, 4, 1, 500), (BCH, 5, 7, 400), (BCH, 8, 1, 300),
+                                            (RS, 8, 1, 300), (RS, 8, 32, 150), (RS, 8, 31, 150), (RS, 5, 12, 300), (BCH, 8, 30, 100)])
+def test_extreme_code_parameters(fam, q, t, frames):
+    """Smallest and largest supported geometries: n = 7, t = 1, 64 syndromes (the per-lane / LDS limits of both
+    algebraic kernels), very low rate."""
+    o = Oracle(fam, q, t)
+    rng = np.random.default_rng(31 * q + t)
+    hi = 2 if fam == BCH else 1 << q
+    cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+    rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, min(o.n, o.t + 3)))) for f in range(frames)])
+    cls = cc.primitive_bch if fam == BCH else cc.rs
+    for alg in (PGZ, BM, EUKLID):
+        code = cls(q, cc.errors(t), TAGS[alg]())
+        assert np.array_equal(code.encode_batch(o.extract(cw)), cw)
+        if alg == EUKLID and t == 32:  # x^2t needs coefficient 64: one lane per coefficient ends at 63
+            with pytest.raises(cc.CcError) as e:
+                code.correct_batch(rx)
+            assert e.value.status == capi.ERR_UNSUPPORTED
+            continue
+        check_against_oracle(code.correct_batch(rx), o, alg, rx)

@@ -281,3 +281,16 @@ def test_host_buffers_match_device_buffers():
     assert np.array_equal(host["iters"].astype(np.int64), dev["iters"].cpu().numpy().astype(np.int64) & 0xFFFF)
     assert np.array_equal(host["status"], dev["status"].cpu().numpy())
     assert 0.2 < (host["status"] == 0).mean() < 0.95
+
+
+@pytest.mark.parametrize("q,t", [(3, 1), (4, 1), (5, 1), (5, 7), (7, 1), (8, 1)])
+def test_minsum_extreme_code_parameters(q, t):
+    """n = 7 (four frames per wavefront in a 16-lane group that is mostly padding), single-error codes with
+    their dense rows, BCH(31,6)."""
+    o = Oracle(BCH, q, t)
+    rng = np.random.default_rng(77 * q + t)
+    cw = o.encode(rng.integers(0, 2, (333, o.l)).astype(np.uint8))
+    y = awgn_llr(rng, cw, o.l / o.n, 5.0)
+    for ov, alpha, beta, rule in ((0, 1.0, 0.0, O2), (1, 0.8, 0.0, O2), (3, 1.0, 0.0, O2), (2, 1.0, 0.01, O1)):
+        code = cc.primitive_bch(q, cc.errors(t), TAG[ov](10, alpha, beta), stop_rule=rule)
+        check(code.correct_batch(y, want_L=True), *o.minsum(ov, 10, y, alpha, beta, rule, fast=True), tag=(q, t, ov))
