@@ -115,3 +115,39 @@ def test_every_code_erasures_multiplication_variants(fam, q):
                 b, L, it, st = o.minsum(ov, 5, y, alpha, 0.0, O2, fast=True)
                 assert np.array_equal(res["out"], b) and np.array_equal(res["L"], L), (q, t, ov, soft.kernel_info())
                 assert np.array_equal(res["iters"], it) and np.array_equal(res["status"] != 0, st != 0), (q, t, ov)
+
+
+def test_batch_sizes_are_prefix_consistent():
+    """Every kernel family (diagonal, register, generic, HBM-state generic, chunked and per-wavefront algebraic,
+    encoder) on ragged batch sizes: decoding the first B frames alone must give the first B rows of the full
+    batch (persistent groups, 32-frame chunks and 4-frames-per-workgroup tails)."""
+    rng = np.random.default_rng(5)
+    sizes = (1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257, 1000)
+    soft = [cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(8)),                  # diagonal kernel
+            cc.primitive_bch(6, cc.errors(3), cc.min_sum_tag(8)),                  # register kernel
+            cc.primitive_bch(4, cc.errors(2), cc.self_correcting_1_min_sum_tag(8)),  # generic, 4 frames per wave
+            cc.primitive_bch(8, cc.errors(20), cc.min_sum_tag(4))]                 # generic, state in HBM
+    for code in soft:
+        y = (1.0 + code.sigma(5.0) * rng.standard_normal((max(sizes), code.n), dtype=np.float32)).astype(np.float32)
+        full = code.correct_batch(y, want_L=True)
+        for B in sizes:
+            part = code.correct_batch(y[:B], want_L=True)
+            for key in ("out", "L", "iters", "status"):
+                assert np.array_equal(part[key], full[key][:B]), (code.to_string(), B, key)
+    hard = [cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag()),   # chunked kernel
+            cc.rs(8, cc.errors(16), cc.euklid_tag()),             # one wavefront per frame
+            cc.primitive_bch(8, cc.errors(3), cc.berlekamp_massey_tag())]
+    for code in hard:
+        hi = 2 if isinstance(code, cc.primitive_bch) else 256
+        msg = rng.integers(0, hi, (max(sizes), code.l)).astype(np.uint8)
+        cw = code.encode_batch(msg)
+        rx = cw.copy()
+        for f in range(len(rx)):
+            for p in rng.choice(code.n, int(rng.integers(0, code.t + 2)), replace=False):
+                rx[f, p] ^= 1 if hi == 2 else int(rng.integers(1, 256))
+        full = code.correct_batch(rx)
+        for B in sizes:
+            assert np.array_equal(code.encode_batch(msg[:B]), cw[:B]), (code.to_string(), B)
+            part = code.correct_batch(rx[:B])
+            for key in ("out", "nerr", "status"):
+                assert np.array_equal(part[key], full[key][:B]), (code.to_string(), B, key)
