@@ -70,6 +70,8 @@ _SIGNATURES = {
     "cc_correct_soft_batch_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_extract_batch": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
     "cc_extract_batch_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
+    "cc_decode_hard_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
+    "cc_decode_soft_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
     "cc_mc_run_dev": (C.c_int, [_VP, C.c_double, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, _VP, _VP]),
     "cc_awgn_llr_dev": (C.c_int, [_VP, C.c_double, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, _VP, _VP, _VP]),
     "cc_sigma": (C.c_double, [_VP, C.c_double]),

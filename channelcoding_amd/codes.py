@@ -367,9 +367,35 @@ class cyclic:
         return dict(out=out, status=status, nerr=nerr)
 
     def decode_batch(self, b, erasures=None):
-        res = self.correct_batch(b, erasures)
-        res["msg"] = self.extract_batch(res["out"])
-        return res
+        """decode = correct + message extraction (cyclic.h:313-327); host arrays go through cc_decode_*_batch."""
+        if _is_torch(b):
+            res = self.correct_batch(b, erasures)
+            res["msg"] = self.extract_batch(res["out"])
+            return res
+        lib = capi.lib()
+        b = np.asarray(b)
+        if b.shape[-1] != self.n:
+            raise CcError(capi.ERR_LENGTH, "decode_batch")
+        B = b.size // self.n
+        er, off = _erasure_csr(erasures, B, self.n)
+        msg = np.zeros((B, self.l), np.uint8)
+        out = np.zeros((B, self.n), np.uint8)
+        status = np.zeros(B, np.int32)
+        if b.dtype.kind in "fi":
+            y = np.ascontiguousarray(b, np.float32).reshape(B, self.n)
+            aux = np.zeros(B, np.uint16 if self.algorithm.soft else np.int32)
+            if self.algorithm.soft:
+                capi.check(lib.cc_decode_soft_batch(self._h, _ptr(y), _ptr(er), _ptr(off), _ptr(msg), _ptr(out),
+                                                    _ptr(aux), _ptr(status), B), "cc_decode_soft_batch")
+                return dict(out=out, msg=msg, status=status, iters=aux)
+            res = self.correct_batch(y, erasures)  # a hard algorithm on channel values: bit = (x < 0), cyclic.h:163-173
+            res["msg"] = self.extract_batch(res["out"])
+            return res
+        sym = np.ascontiguousarray(b, np.uint8).reshape(B, self.n)
+        nerr = np.zeros(B, np.int32)
+        capi.check(lib.cc_decode_hard_batch(self._h, _ptr(sym), _ptr(er), _ptr(off), _ptr(msg), _ptr(out), _ptr(nerr),
+                                            _ptr(status), B), "cc_decode_hard_batch")
+        return dict(out=out, msg=msg, status=status, nerr=nerr)
 
     # ---- single-frame API with the reference's exception behaviour ----
     _MESSAGES = {

@@ -592,6 +592,48 @@ int cc_extract_batch(const cc_code *code, const uint8_t *cw, uint8_t *msg, size_
   return byte_map_host(code, false, cw, msg, B);
 }
 
+/* ------------------------------ decode = correct + extract ------------------------------ */
+
+static int decode_host(const cc_code *code, bool float_in, const void *in, const uint16_t *erasures,
+                       const uint32_t *erasure_offsets, uint8_t *msg, uint8_t *words, uint16_t *iters, int32_t *nerr,
+                       int32_t *status, size_t B) {
+  if (!code || (B && (!in || !msg))) return CC_ERR_INVALID_ARGUMENT;
+  if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (B == 0) return CC_OK;
+  std::vector<uint8_t> tmp;
+  if (!words) {
+    tmp.resize(B * code->tab.n);
+    words = tmp.data();
+  }
+  int rc;
+  if (code->soft) {
+    if (!float_in) {
+      set_last_error("min-sum needs a signed (soft) input sequence");
+      return CC_ERR_INVALID_ARGUMENT;
+    }
+    rc = cc_correct_soft_batch(code, static_cast<const float *>(in), erasures, erasure_offsets, words, nullptr, iters,
+                               status, B);
+  } else if (float_in) {
+    if (erasures) return CC_ERR_UNSUPPORTED;
+    rc = cc_correct_hard_f32_batch(code, static_cast<const float *>(in), words, nerr, status, B);
+  } else {
+    rc = cc_correct_hard_batch(code, static_cast<const uint8_t *>(in), erasures, erasure_offsets, words, nerr, status, B);
+  }
+  if (rc != CC_OK) return rc;
+  return cc_extract_batch(code, words, msg, B);
+}
+
+int cc_decode_hard_batch(const cc_code *code, const uint8_t *in, const uint16_t *erasures,
+                         const uint32_t *erasure_offsets, uint8_t *msg, uint8_t *words, int32_t *nerr, int32_t *status,
+                         size_t B) {
+  return decode_host(code, false, in, erasures, erasure_offsets, msg, words, nullptr, nerr, status, B);
+}
+
+int cc_decode_soft_batch(const cc_code *code, const float *y, const uint16_t *erasures, const uint32_t *erasure_offsets,
+                         uint8_t *msg, uint8_t *words, uint16_t *iters, int32_t *status, size_t B) {
+  return decode_host(code, true, y, erasures, erasure_offsets, msg, words, iters, nullptr, status, B);
+}
+
 /* ------------------------------ Monte-Carlo ------------------------------ */
 
 static int mc_supported(const cc_code *code) {

@@ -181,6 +181,16 @@ int cc_correct_soft_batch_dev(const cc_code *code, const float *d_llr, const uin
 /* ---- decode = correct + message extraction: cyclic::decode cyclic.h:313-327 (+ free decode :42-51) ---- */
 int cc_extract_batch(const cc_code *code, const uint8_t *cw /* B*n */, uint8_t *msg /* B*l */, size_t B);
 int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, void *stream);
+/* decode<InputSequence, Return_type>(b, erasures) in one call (cyclic.h:313-327): correct, then take the message
+ * of the corrected word (failed frames: of the hard-decided input, as cc_correct_* leaves it).  The input is
+ * symbols for cc_decode_hard_batch, signed channel values for cc_decode_soft_batch -- with a hard algorithm the
+ * latter takes bit = (x < 0) first (cyclic.h:163-173) and erasures must be NULL; words may be NULL. */
+int cc_decode_hard_batch(const cc_code *code, const uint8_t *in /* B*n */, const uint16_t *erasures,
+                         const uint32_t *erasure_offsets, uint8_t *msg /* B*l */, uint8_t *words /* B*n or NULL */,
+                         int32_t *nerr, int32_t *status, size_t B);
+int cc_decode_soft_batch(const cc_code *code, const float *y /* B*n */, const uint16_t *erasures,
+                         const uint32_t *erasure_offsets, uint8_t *msg /* B*l */, uint8_t *words /* B*n or NULL */,
+                         uint16_t *iters, int32_t *status, size_t B);
 
 /* ---- batched AWGN Monte-Carlo (replaces awgn_simulation::operator(), src/simulation/simulation.c++:95-150).
  *      Frames [first_frame, first_frame + frames) of one Eb/N0 point are generated ON DEVICE (Philox4x32-10

@@ -233,6 +233,7 @@ struct batch_result {
   std::vector<int32_t> nerr;    // hard algorithms: corrected symbols or -1
   std::vector<uint16_t> iters;  // soft algorithms: index of the returning iteration
   std::vector<float> L;         // soft algorithms, when requested
+  std::vector<uint8_t> msg;     // decode_batch: B * l message symbols
 };
 
 template <int Family, unsigned q, typename Capability, typename Algorithm, unsigned N, typename Coding, unsigned mu,
@@ -371,6 +372,30 @@ public:
       detail::check(cc_correct_hard_f32_batch(handle.get(), values, r.words.data(), r.nerr.data(), r.status.data(), B),
                     "cc_correct_hard_f32_batch");
     }
+    return r;
+  }
+
+  // decode = correct + message extraction for B frames (cc_decode_hard_batch / cc_decode_soft_batch)
+  batch_result decode_batch(const uint8_t *symbols, size_t B) const {
+    batch_result r;
+    r.words.resize(B * n);
+    r.msg.resize(B * l);
+    r.status.resize(B);
+    r.nerr.resize(B);
+    detail::check(cc_decode_hard_batch(handle.get(), symbols, nullptr, nullptr, r.msg.data(), r.words.data(), r.nerr.data(),
+                                       r.status.data(), B),
+                  "cc_decode_hard_batch");
+    return r;
+  }
+  batch_result decode_batch(const float *values, size_t B) const {
+    batch_result r;
+    r.words.resize(B * n);
+    r.msg.resize(B * l);
+    r.status.resize(B);
+    if (soft) r.iters.resize(B);
+    detail::check(cc_decode_soft_batch(handle.get(), values, nullptr, nullptr, r.msg.data(), r.words.data(),
+                                       soft ? r.iters.data() : nullptr, r.status.data(), B),
+                  "cc_decode_soft_batch");
     return r;
   }
 

@@ -107,6 +107,23 @@ int main() try {
     for (int f = 0; f < 1000; f++)
       if (res.status[f] != CC_FRAME_OK || res.iters[f] != 0 || res.L[f * 15] != 0.7f) throw std::runtime_error("batch");
     std::printf("ok   batch of 1000 soft frames\n");
+    const auto dec = soft.decode_batch(batch.data(), 1000);
+    const auto one = soft.decode<std::vector<float>, uint8_t>(y);
+    for (int f = 0; f < 1000; f++)
+      for (unsigned j = 0; j < one.size(); j++)
+        if (dec.msg[f * one.size() + j] != one[j]) throw std::runtime_error("decode_batch (soft)");
+    std::vector<uint8_t> words, clean;
+    code.encode(msg, std::back_inserter(clean));
+    for (int f = 0; f < 50; f++) {
+      std::vector<uint8_t> w(clean);
+      w[f % 15] ^= 1;
+      words.insert(words.end(), w.begin(), w.end());
+    }
+    const auto hd = code.decode_batch(words.data(), 50);
+    for (int f = 0; f < 50; f++)
+      for (unsigned j = 0; j < msg.size(); j++)
+        if (hd.status[f] != CC_FRAME_OK || hd.msg[f * msg.size() + j] != msg[j]) throw std::runtime_error("decode_batch (hard)");
+    std::printf("ok   decode_batch\n");
   }
   {  // H_alt (cyclic.h:361-385) and the free min_sum<R, U>(H, y, tag) of soft_decision.h:220-295
     cyclic::primitive_bch<4, errors<2>, min_sum_tag<10>> code;

@@ -108,3 +108,35 @@ def test_multiplication_tag_golden(cid):
             bad[f, p] ^= 1 if fam == BCH else int(rng.integers(1, hi))
     res = code.decode_batch(bad)
     assert (res["status"] == 0).all() and np.array_equal(res["msg"], msg)
+
+
+def test_decode_entry_points():
+    """cc_decode_hard_batch / cc_decode_soft_batch = correct + extract (cyclic::decode, cyclic.h:313-327)."""
+    rng = np.random.default_rng(17)
+    for cid, alg in ((10, cc.berlekamp_massey_tag()), (6, cc.euklid_tag()), (9, cc.peterson_gorenstein_zierler_tag())):
+        fam, q, t = REF_CODES[cid]
+        o = Oracle(fam, q, t)
+        code = make_code(cid, alg)
+        hi = 2 if fam == BCH else 1 << q
+        msg = rng.integers(0, hi, (500, o.l)).astype(np.uint8)
+        rx = o.encode(msg)
+        injected = rng.integers(0, t + 3, len(rx))
+        for f in range(len(rx)):
+            for p in rng.choice(o.n, int(injected[f]), replace=False):
+                rx[f, p] ^= 1 if fam == BCH else int(rng.integers(1, hi))
+        a = code.decode_batch(rx)
+        b = code.correct_batch(rx)
+        assert np.array_equal(a["out"], b["out"]) and np.array_equal(a["status"], b["status"])
+        assert np.array_equal(a["nerr"], b["nerr"]) and np.array_equal(a["msg"], o.extract(b["out"]))
+        ok = a["status"] == 0
+        easy = injected <= t  # beyond t a decoder may land on another codeword
+        assert ok[easy].all() and (~ok).any() and np.array_equal(a["msg"][easy], msg[easy])
+    soft = cc.primitive_bch(6, cc.errors(3), cc.normalized_min_sum_tag(10, 0.8))
+    o = Oracle(BCH, 6, 3)
+    msg = rng.integers(0, 2, (400, o.l)).astype(np.uint8)
+    y = (1.0 - 2.0 * o.encode(msg) + soft.sigma(5.0) * rng.standard_normal((400, 63))).astype(np.float32)
+    a, b = soft.decode_batch(y), soft.correct_batch(y)
+    assert np.array_equal(a["out"], b["out"]) and np.array_equal(a["iters"], b["iters"])
+    assert np.array_equal(a["msg"], b["out"][:, soft.k:])
+    hardf = cc.primitive_bch(6, cc.errors(3), cc.berlekamp_massey_tag()).decode_batch(y)
+    assert np.array_equal(hardf["msg"], hardf["out"][:, soft.k:]) and (hardf["status"] == 0).any()
