@@ -343,7 +343,7 @@ def main():
                 "frac": frame_iters * cyc / (SIMDS * CLOCK_HZ),
                 "note": "fraction of all SIMD issue cycles spent issuing this kernel's VALU instructions",
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would idle at the barrier
             out["cpu_baseline"] = cpu_baseline(y[:32768].cpu().numpy(), args.iterations)
         else:
             out["cpu_baseline"] = None
