@@ -263,3 +263,27 @@ def test_extreme_code_parameters(fam, q, t, frames):
             assert e.value.status == capi.ERR_UNSUPPORTED
             continue
         check_against_oracle(code.correct_batch(rx), o, alg, rx)
+
+
+@pytest.mark.parametrize("fam,q,t,frames", [(RS, 4, 4, 30000), (RS, 5, 4, 20000), (RS, 5, 8, 8000), (BCH, 6, 4, 20000)])
+def test_recheck_paths_of_the_chunked_kernel(fam, q, t, frames):
+    """Codes with at least 8 syndromes run algebraic_chunk_kernel; random words and heavy error patterns make its
+    rare branches fire (L != deg lambda -> explicit re-check, re-check failures, PGZ degree bound)."""
+    o = Oracle(fam, q, t)
+    rng = np.random.default_rng(777 + 31 * q + t)
+    hi = 2 if fam == BCH else 1 << q
+    cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+    rx = cw.copy()
+    half = frames // 2
+    rx[:half] = rng.integers(0, hi, (half, o.n))
+    for f in range(half, frames):
+        rx[f] = corrupt(rng, o, cw[f], int(rng.integers(0, min(o.n, 3 * o.t))))
+    cls = cc.primitive_bch if fam == BCH else cc.rs
+    for alg in (BM, PGZ):
+        code = cls(q, cc.errors(t), TAGS[alg]())
+        assert code.kernel_info()["kernel"].startswith("algebraic_chunk_kernel")
+        check_against_oracle(code.correct_batch(rx), o, alg, rx)
+    st = cls(q, cc.errors(t), TAGS[BM]()).correct_batch(rx)["status"]
+    assert (st == 0).any() and (st == 2).any()
+    if fam == RS and t == 4:
+        assert (st == 3).any()
