@@ -229,9 +229,8 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     }
     CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
     CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (code->custom_H.empty() && t.n == 255 && t.k <= 32 && t.row0_support.size() % 16 == 0 &&
-        t.row0_support.size() / 16 == 7) {
-      const std::vector<uint16_t> dg = build_diag_table(t, 7);
+    if (const DiagGeometry *dgeo = code->custom_H.empty() ? diag_geometry(t) : nullptr) {
+      const std::vector<uint16_t> dg = build_diag_table(t, dgeo->D, dgeo->LPF);
       std::vector<uint32_t> cb(256, 0u);
       for (unsigned j = 0; j < t.n; ++j)
         for (unsigned i = 0; i < t.k && i <= j; ++i)

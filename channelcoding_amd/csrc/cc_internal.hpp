@@ -62,7 +62,7 @@ struct cc_code {
   unsigned ms_rows = 0;           // check nodes of the min-sum graph (tab.k unless custom_H)
   ccamd::MinSumGeometry geo;
   uint32_t *d_colmask = nullptr;
-  uint16_t *d_diag = nullptr;    // [D][16] diagonal (row-0 support) dealt to 16 lanes x D slots (minsum_diag)
+  uint16_t *d_diag = nullptr;    // [D][LPF] diagonals (row-0 support) dealt to LPF lanes x D slots (minsum_diag)
   uint32_t *d_colbits = nullptr;  // [256] per column: bit i = H[i][col]
   uint8_t *d_parity = nullptr;  // k x l table of x^(k+j) mod g (division_tag encoder)
   uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
@@ -95,9 +95,15 @@ int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d
                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                       size_t B, hipStream_t stream);
 // minsum_diag.hip
-std::vector<uint16_t> build_diag_table(const CodeTables &t, int D);
+struct DiagGeometry {
+  unsigned n, k, w;  // code length, rows of H, row weight
+  int D, LPF, CPL;   // diagonals per lane, lanes per frame, columns per lane
+};
+const DiagGeometry *diag_geometry(const CodeTables &t);  // nullptr: no diagonal kernel for this code
+std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W);
+size_t minsum_diag_lds_bytes(const DiagGeometry &g);
 bool minsum_diag_supported(const cc_code *code);
-const char *minsum_diag_name(const cc_code *code);
+std::string minsum_diag_name(const cc_code *code);
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                        size_t B, hipStream_t stream);

@@ -261,10 +261,11 @@ size_t generic_lds_bytes(const cc_code *code) {
 int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_per_wg, uint32_t &threads,
                        uint32_t &lds) {
   if (minsum_diag_supported(code) && !code->force_generic) {
+    const DiagGeometry *dg = diag_geometry(code->tab);
     name = minsum_diag_name(code);
-    frames_per_wg = 16;
+    frames_per_wg = static_cast<uint32_t>(4 * 64 / dg->LPF);
     threads = 256;
-    lds = 4 * (4 * 272 * 12) + 1024;
+    lds = static_cast<uint32_t>(minsum_diag_lds_bytes(*dg));
     return CC_OK;
   }
   if (minsum_reg_supported(code) && !code->force_generic) {

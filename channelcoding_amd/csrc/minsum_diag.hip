@@ -37,7 +37,6 @@ namespace ccamd {
 namespace {
 
 
-constexpr int kRegionCols = 272;  // 256 columns + 16 pad: odd frames start 16 banks later
 
 // compile-time loop: indices are literal constants from the start, so the register arrays below are
 // scalarised by SROA before any unrolling heuristics get a say (a partially unrolled loop over R[K][D]
@@ -79,8 +78,8 @@ __device__ __forceinline__ uint32_t xor_stage(uint32_t v) { return v ^ dpp16<CTR
 template <int CTRL>
 __device__ __forceinline__ uint32_t or_stage(uint32_t v) { return v | dpp16<CTRL, 0u>(v); }
 
-// RB rows reduced together, stage-major (independent DPP ops back to back)
-template <int RB>
+// RB rows reduced together, stage-major (independent DPP ops back to back); LPF = lanes per frame (8 or 16)
+template <int RB, int LPF>
 __device__ __forceinline__ void row_allreduce(uint32_t (&m1)[RB], uint32_t (&m2)[RB], uint32_t (&sg)[RB]) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -92,21 +91,25 @@ __device__ __forceinline__ void row_allreduce(uint32_t (&m1)[RB], uint32_t (&m2)
 #pragma unroll
   for (int r = 0; r < RB; ++r) { pair_stage<0x141>(m1[r], m2[r]); sg[r] = xor_stage<0x141>(sg[r]); }  // row_half_mirror
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (LPF == 16) {
 #pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0x140>(m1[r], m2[r]); sg[r] = xor_stage<0x140>(sg[r]); }  // row_mirror
-  __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < RB; ++r) { pair_stage<0x140>(m1[r], m2[r]); sg[r] = xor_stage<0x140>(sg[r]); }  // row_mirror
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
+template <int LPF>
 __device__ __forceinline__ uint32_t group_xor(uint32_t v) {
   v = xor_stage<0xB1>(v);
   v = xor_stage<0x4E>(v);
   v = xor_stage<0x141>(v);
-  return xor_stage<0x140>(v);
+  return LPF == 16 ? xor_stage<0x140>(v) : v;
 }
+template <int LPF>
 __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   v = or_stage<0xB1>(v);
   v = or_stage<0x4E>(v);
   v = or_stage<0x141>(v);
-  return or_stage<0x140>(v);
+  return LPF == 16 ? or_stage<0x140>(v) : v;
 }
 
 template <int VARIANT>
@@ -121,24 +124,28 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
   }
 }
 
-// K rows, D diagonals per lane (16 * D = row weight), RB rows per reduction batch, 16 columns per lane
-template <int K, int D, int VARIANT, int RB>
-__global__ void __launch_bounds__(256, 2)
+// K rows, D diagonals per lane (LPF * D = row weight), RB rows per reduction batch, LPF lanes per frame (64 / LPF
+// frames per wavefront), CPL columns per lane (LPF * CPL >= n), OCC = waves per SIMD the register budget targets
+template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC>
+__global__ void __launch_bounds__(256, OCC)
 minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
                    const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
                    uint8_t *__restrict__ hard, float *__restrict__ Lout, uint16_t *__restrict__ iters_out,
                    int32_t *__restrict__ status_out, unsigned long long B) {
   static_assert(K % RB == 0 && K <= 32, "row batching");
+  static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
+  constexpr int FPW = 64 / LPF;          // frames per wavefront
+  constexpr int RC = LPF * CPL + 16;     // columns of one frame's LDS region (+16 pad: odd frames start 16 banks later)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // CY: one float2 {cs, y} per column, frame f at f * kRegionCols.  CN: one float per column at an 8-byte
+  // CY: one float2 {cs, y} per column, frame f at f * RC.  CN: one float per column at an 8-byte
   // stride, the two frames of a 32-lane half interleaved on even / odd dwords (conflict-free, and the byte
   // offset of a slot differs from its CY offset by a per-lane constant: one address register per slot).
-  constexpr int CY_BYTES = 4 * kRegionCols * 8, CN_BYTES = 2 * kRegionCols * 8;
+  constexpr int CY_BYTES = FPW * RC * 8, CN_BYTES = (FPW / 2) * RC * 8;
   constexpr int WAVE_BYTES = CY_BYTES + CN_BYTES;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int fl = lane >> 4, lam = lane & 15;
+  const int fl = lane / LPF, lam = lane & (LPF - 1);
   char *cy_base = smem + wid * WAVE_BYTES;
-  char *cn_lane = cy_base + CY_BYTES + ((fl >> 1) - fl) * kRegionCols * 8 + (fl & 1) * 4;  // + aCY[d] -> CN slot
+  char *cn_lane = cy_base + CY_BYTES + ((fl >> 1) - fl) * RC * 8 + (fl & 1) * 4;  // + aCY[d] -> CN slot
   uint32_t *cbits = reinterpret_cast<uint32_t *>(smem + 4 * WAVE_BYTES);  // [256] per workgroup
   cbits[threadIdx.x] = colbits[threadIdx.x];
   __syncthreads();
@@ -147,11 +154,11 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   // byte offsets of this lane's D diagonals (row 0) and of its 16 owned columns
   int aCY[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) aCY[d] = (fl * kRegionCols + diag_s[d * 16 + lam]) * 8;
-  const int col0 = fl * kRegionCols + lam;  // owned columns: lam + 16 c
+  for (int d = 0; d < D; ++d) aCY[d] = (fl * RC + diag_s[d * LPF + lam]) * 8;
+  const int col0 = fl * RC + lam;  // owned columns: lam + LPF c
 
-  const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 16;
-  unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * 4 + fl;
+  const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
+  unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * FPW + fl;
   bool active = frame < B;
   bool need_load = true;
   unsigned it = 0;
@@ -159,24 +166,24 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
   while (__any(active)) {
     if (need_load && active) {  // per 16-lane group
-      float yv[16];
+      float yv[CPL];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int j = lam + 16 * c;
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lam + LPF * c;
         yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
       }
       if (er_off != nullptr) {  // cyclic.h:259-262
         for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
           const int pos = er[e];
 #pragma unroll
-          for (int c = 0; c < 16; ++c)
-            if (pos == lam + 16 * c) yv[c] = 0.0f;
+          for (int c = 0; c < CPL; ++c)
+            if (pos == lam + LPF * c) yv[c] = 0.0f;
         }
       }
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        *reinterpret_cast<float2 *>(cy_base + (col0 + 16 * c) * 8) = make_float2(0.0f, yv[c]);
-        *reinterpret_cast<float *>(cn_lane + (col0 + 16 * c) * 8) = 0.0f;
+      for (int c = 0; c < CPL; ++c) {
+        *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, yv[c]);
+        *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
       }
       static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
       it = 0;
@@ -223,7 +230,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD] + 8 * (i + 1)); });
       float cn[D];
       static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
-      row_allreduce<1>(m1, m2, sg);
+      row_allreduce<1, LPF>(m1, m2, sg);
       const uint32_t sign31 = sg[0] & 0x80000000u;
       if constexpr (VARIANT == CC_ALG_MS) {
         const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
@@ -278,7 +285,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         m2[ii] = f2u(a2);
         sg[ii] = s;
       });
-      row_allreduce<RB>(m1, m2, sg);
+      row_allreduce<RB, LPF>(m1, m2, sg);
       static_for<RB>([&](auto II) {
         constexpr int ii = II, i = rb * RB + ii;
         const uint32_t sign31 = sg[ii] & 0x80000000u;  // parity of the row's negative messages (q is never -0.0f)
@@ -311,32 +318,32 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
     uint32_t pv = 0, any = 0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int j = lam + 16 * c;
-      const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + 16 * c) * 8);
-      const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + 16 * c) * 8 + 4);
+    for (int c = 0; c < CPL; ++c) {
+      const int j = lam + LPF * c;
+      const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
+      const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
       const bool bit = (j < n) && (cnv + yc < 0.0f);  // L = cs + y :180-182, b = L < 0 codes.h:51
       const uint32_t cb = cbits[j];
       pv ^= bit ? cb : 0u;
       any |= bit ? cb : 0u;
       // next iteration: cs := cs', cs' := 0
-      *reinterpret_cast<float *>(cy_base + (col0 + 16 * c) * 8) = cnv;
-      *reinterpret_cast<float *>(cn_lane + (col0 + 16 * c) * 8) = 0.0f;
+      *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
+      *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
     }
     bool ok;
     if (p.stop_rule == CC_STOP_AS_SHIPPED)
       ok = true;
     else if (p.stop_rule == CC_STOP_PARITY)
-      ok = group_xor(pv) == 0;
+      ok = group_xor<LPF>(pv) == 0;
     else
-      ok = group_or(any) == 0;
+      ok = group_or<LPF>(any) == 0;
     const bool finished = ok || (it + 1 >= p.iterations);
     if (finished && active) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int j = lam + 16 * c;
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lam + LPF * c;
         if (j < n) {
-          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + 16 * c) * 8);  // {cs (new), y}
+          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
           const float Lc = cy.x + cy.y;
           hard[frame * n + j] = (Lc < 0.0f) ? 1 : 0;
           if (Lout) Lout[frame * n + j] = Lc;
@@ -357,11 +364,23 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 }  // namespace
 
-// Deal the row-0 support (w = 16 * D diagonals) to 16 lanes x D slots so that, within a slot, the 16
-// values are as distinct as possible modulo 16: LDS has 32 banks, two frames share a 32-lane half and
-// the odd frame's region starts 16 banks later, so residues mod 16 decide bank conflicts.
-std::vector<uint16_t> build_diag_table(const CodeTables &t, int D) {
-  const int W = 16;
+// Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
+// in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
+static const DiagGeometry kDiagGeometries[] = {
+    // n,   k,  w,  D, LPF, CPL
+    {255, 24, 112, 7, 16, 16},  // BCH(255,231)
+    {63, 18, 24, 3, 8, 8},      // BCH(63,45)
+};
+const DiagGeometry *diag_geometry(const CodeTables &t) {
+  for (const DiagGeometry &g : kDiagGeometries)
+    if (t.n == g.n && t.k == g.k && t.row0_support.size() == g.w) return &g;
+  return nullptr;
+}
+
+// Deal the row-0 support (w = W * D diagonals) to W lanes x D slots so that, within a slot, the W values are as
+// distinct as possible modulo 16: the frames of a 32-lane half sit in regions that start 16 banks apart, so
+// residues mod 16 decide bank conflicts.
+std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
   std::vector<std::vector<unsigned>> cls(W);
   for (unsigned s : t.row0_support) cls[s % W].push_back(s);
   std::vector<std::vector<unsigned>> grp(D);
@@ -393,7 +412,7 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D) {
   // largest number of lanes on one residue class -- the LDS passes a slot instruction needs) decreases
   auto group_cost = [&](const std::vector<unsigned> &g) {
     int cnt[16] = {0}, mx = 0, sq = 0;
-    for (unsigned s : g) ++cnt[s % W];
+    for (unsigned s : g) ++cnt[s % 16];
     for (int c : cnt) {
       mx = c > mx ? c : mx;
       sq += c * c;
@@ -432,7 +451,7 @@ bool minsum_diag_supported(const cc_code *code) {
   if (alg == CC_ALG_OMS && !(code->desc.beta >= 0.0)) return false;
   const float a = static_cast<float>(code->desc.alpha);
   if ((alg == CC_ALG_NMS || alg == CC_ALG_2DNMS) && !(a == a && a - a == 0.0f)) return false;
-  return code->tab.k == 24 && code->tab.row0_support.size() == 112 && code->tab.n == 255;
+  return diag_geometry(code->tab) != nullptr;
 }
 
 #ifndef CC_DIAG_PIPELINE
@@ -441,29 +460,43 @@ bool minsum_diag_supported(const cc_code *code) {
 #ifndef CC_DIAG_RB
 #define CC_DIAG_RB 2
 #endif
-#define CC_STR2(x) #x
-#define CC_STR(x) CC_STR2(x)
-const char *minsum_diag_name(const cc_code *) {
-  return CC_DIAG_PIPELINE ? "minsum_diag_kernel<K=24,D=7,row-pipelined>" : "minsum_diag_kernel<K=24,D=7,RB=" CC_STR(CC_DIAG_RB) ">";
+
+std::string minsum_diag_name(const cc_code *code) {
+  const DiagGeometry *g = diag_geometry(code->tab);
+  if (!g) return "minsum_diag_kernel";
+  return "minsum_diag_kernel<K=" + std::to_string(g->k) + ",D=" + std::to_string(g->D) + ",LPF=" +
+         std::to_string(g->LPF) + (CC_DIAG_PIPELINE ? ",row-pipelined>" : ">");
 }
 
-int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
-                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
-                       size_t B, hipStream_t stream) {
-  constexpr int K = 24, D = 7, RB = CC_DIAG_RB;
-  const size_t lds = 4 * (4 * kRegionCols * 8 + 2 * kRegionCols * 8) + 256 * 4;
-  const unsigned long long blocks_needed = (B + 15) / 16;
-  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 2;  // 2 resident blocks per CU
+size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
+  const size_t fpw = 64 / g.LPF, rc = static_cast<size_t>(g.LPF) * g.CPL + 16;
+  return 4 * (fpw * rc * 8 + (fpw / 2) * rc * 8) + 256 * 4;
+}
+
+namespace {
+
+template <int K, int D, int LPF, int CPL, int OCC>
+int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
+                         const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
+                         size_t B, hipStream_t stream) {
+  constexpr int RB = (K % CC_DIAG_RB == 0) ? CC_DIAG_RB : 1;
+  constexpr int FPW = 64 / LPF;
+  const DiagGeometry g{0, 0, 0, D, LPF, CPL};
+  const size_t lds = minsum_diag_lds_bytes(g);
+  const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
+  unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
+  if (per_cu > static_cast<unsigned long long>(OCC)) per_cu = OCC;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
 #define CC_LAUNCH(V)                                                                                                 \
   {                                                                                                                  \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB>),                        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>),         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                      \
     if (e == hipSuccess)                                                                                             \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB>), dim3(grid), dim3(256), lds, stream, p, code->d_diag,     \
-                         code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);                \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>), dim3(grid), dim3(256), lds, stream, p,    \
+                         code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);  \
   }                                                                                                                  \
   break
   switch (p.variant) {
@@ -477,6 +510,22 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "minsum_diag kernel launch");
   return CC_OK;
+}
+
+}  // namespace
+
+int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
+                       const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
+                       size_t B, hipStream_t stream) {
+  const DiagGeometry *g = diag_geometry(code->tab);
+  if (!g) return CC_ERR_UNSUPPORTED;
+#define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
+  if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
+  return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
+  CC_GEO(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD
+  CC_GEO(18, 3, 8, 8, 4);    // BCH(63,45): 54 message registers, eight frames per wavefront
+#undef CC_GEO
+  return CC_ERR_UNSUPPORTED;
 }
 
 }  // namespace ccamd
