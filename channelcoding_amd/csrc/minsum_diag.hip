@@ -1,375 +1,24 @@
-// minsum_diag.hip -- diagonal-parallel min-sum kernel: 16 lanes per codeword, four codewords per
-// wavefront, every (lane, slot, row) triple is a real edge of H.
-//
-// Why (measured on MI355X, profiles/r01_ubench_instruction_rates.txt): only f32 add/sub/mul issue at
-// ~2.5 cycles per wave instruction; every other VALU op (min/max/med3, integer, compare, select, DPP)
-// costs ~4.3.  The column-parallel register kernel (minsum_reg.hip) spends 96 slot-instructions per
-// frame-iteration at 44 % lane utilisation (H is a band of density 112/255) plus 2 x 6 DPP stages per
-// row for ONE frame.  Here:
-//   * H is banded Toeplitz (cyclic.h:346-359): edge (row i, diagonal s) sits in column s + i.  The
-//     w = 112 diagonals of BCH(255,231) are dealt 7 to each of 16 lanes, so a frame costs 7 x 24 dense
-//     slot-instructions shared by the 4 frames of the wave (42 per frame-iteration), no EXEC masks,
-//     no scalar mask loads;
-//   * a row reduction is a 4-stage all-reduce inside a 16-lane DPP row, shared by 4 frames;
-//   * per-edge messages r/q stay in VGPRs (168 per lane); the per-column state lives in LDS:
-//       CY[col] = {cs, y}   column sums of the previous iteration and the channel value (one ds_read_b64)
-//       CN[col] = cs'       column sums being accumulated, read-modify-written row by row in ascending
-//                           row order -- the reference's summation order (soft_decision.h:88-95).
-//     Within one row all 112 diagonals hit distinct columns, successive rows are ordered by program
-//     order (LDS operations of a wave execute in order), so no atomics are needed.
-//   * 16-lane groups are persistent: a group that converged (or ran out of iterations) stores its
-//     frame and loads the next one while the other three groups keep iterating.
-//
-// Numerics are those of minsum_reg.hip (same exclusive-minimum / sign identities, same argument for
-// zeros); configurations outside that argument use the generic kernel.
-#include <cstdio>
-#include <cstdlib>
-#include <utility>
-
-#include "cc_internal.hpp"
-#include "wave_ops.hpp"
-
-#ifndef CC_DIAG_PIPELINE
-#define CC_DIAG_PIPELINE 1
-#endif
+// minsum_diag.hip -- host side of the diagonal-parallel min-sum kernel (geometry table, dealing of the diagonals
+// to lanes, dispatch) and the instantiations for n = 255 and n = 127; the kernel itself is minsum_diag_impl.hpp,
+// the instantiations for n <= 63 are compiled in minsum_diag_small.hip (two translation units build in parallel).
+#include "minsum_diag_impl.hpp"
 
 namespace ccamd {
-namespace {
-
-
-
-// compile-time loop: indices are literal constants from the start, so the register arrays below are
-// scalarised by SROA before any unrolling heuristics get a say (a partially unrolled loop over R[K][D]
-// sends the array to scratch memory)
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
-}
-// (a ^ b) + c in one VALU op
-__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t r;
-  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
-template <int CTRL, uint32_t IDENT>
-__device__ __forceinline__ uint32_t dpp16(uint32_t v) {
-  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(IDENT), static_cast<int>(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
-
-// one butterfly stage of the (min1, min2-with-multiplicity) all-reduce inside a 16-lane row
-template <int CTRL>
-__device__ __forceinline__ void pair_stage(uint32_t &m1, uint32_t &m2) {
-  // all four patterns used here (quad_perm, row_half_mirror, row_mirror) read a valid lane everywhere, so the
-  // `old` operand is never selected: mov_dpp leaves it undefined, update_dpp(m2, m2) would cost a v_mov to tie it
-  const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m2), CTRL, 0xF, 0xF, true));
-  const uint32_t lo = umin32(m1, dpp16<CTRL, 0xFFFFFFFFu>(m1));
-  const uint32_t hi = umax32(m1, dpp16<CTRL, 0u>(m1));
-  m1 = lo;
-  m2 = umin32(hi, umin32(m2, o2));
-}
-template <int CTRL>
-__device__ __forceinline__ uint32_t xor_stage(uint32_t v) { return v ^ dpp16<CTRL, 0u>(v); }
-template <int CTRL>
-__device__ __forceinline__ uint32_t or_stage(uint32_t v) { return v | dpp16<CTRL, 0u>(v); }
-
-// RB rows reduced together, stage-major (independent DPP ops back to back); LPF = lanes per frame (8 or 16)
-template <int RB, int LPF>
-__device__ __forceinline__ void row_allreduce(uint32_t (&m1)[RB], uint32_t (&m2)[RB], uint32_t (&sg)[RB]) {
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0xB1>(m1[r], m2[r]); sg[r] = xor_stage<0xB1>(sg[r]); }   // quad_perm [1,0,3,2]
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0x4E>(m1[r], m2[r]); sg[r] = xor_stage<0x4E>(sg[r]); }   // quad_perm [2,3,0,1]
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0x141>(m1[r], m2[r]); sg[r] = xor_stage<0x141>(sg[r]); }  // row_half_mirror
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (LPF == 16) {
-#pragma unroll
-    for (int r = 0; r < RB; ++r) { pair_stage<0x140>(m1[r], m2[r]); sg[r] = xor_stage<0x140>(sg[r]); }  // row_mirror
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-template <int LPF>
-__device__ __forceinline__ uint32_t group_xor(uint32_t v) {
-  v = xor_stage<0xB1>(v);
-  v = xor_stage<0x4E>(v);
-  v = xor_stage<0x141>(v);
-  return LPF == 16 ? xor_stage<0x140>(v) : v;
-}
-template <int LPF>
-__device__ __forceinline__ uint32_t group_or(uint32_t v) {
-  v = or_stage<0xB1>(v);
-  v = or_stage<0x4E>(v);
-  v = or_stage<0x141>(v);
-  return LPF == 16 ? or_stage<0x140>(v) : v;
-}
-
-template <int VARIANT>
-__device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_d) {
-  if constexpr (VARIANT == CC_ALG_NMS || VARIANT == CC_ALG_2DNMS) {
-    return __fmul_rn(alpha_f, m);
-  } else if constexpr (VARIANT == CC_ALG_OMS) {
-    const double a = static_cast<double>(m) - beta_d;
-    return static_cast<float>((a < 0.0) ? 0.0 : a);
-  } else {
-    return m;
-  }
-}
-
-// K rows, D diagonals per lane (LPF * D = row weight), RB rows per reduction batch, LPF lanes per frame (64 / LPF
-// frames per wavefront), CPL columns per lane (LPF * CPL >= n), OCC = waves per SIMD the register budget targets
-template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC>
-__global__ void __launch_bounds__(256, OCC)
-minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
-                   const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
-                   uint8_t *__restrict__ hard, float *__restrict__ Lout, uint16_t *__restrict__ iters_out,
-                   int32_t *__restrict__ status_out, unsigned long long B) {
-  static_assert(K % RB == 0 && K <= 32, "row batching");
-  static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
-  constexpr int FPW = 64 / LPF;          // frames per wavefront
-  constexpr int RC = LPF * CPL + 16;     // columns of one frame's LDS region (+16 pad: odd frames start 16 banks later)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // CY: one float2 {cs, y} per column, frame f at f * RC.  CN: one float per column at an 8-byte
-  // stride, the two frames of a 32-lane half interleaved on even / odd dwords (conflict-free, and the byte
-  // offset of a slot differs from its CY offset by a per-lane constant: one address register per slot).
-  constexpr int CY_BYTES = FPW * RC * 8, CN_BYTES = (FPW / 2) * RC * 8;
-  constexpr int WAVE_BYTES = CY_BYTES + CN_BYTES;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int fl = lane / LPF, lam = lane & (LPF - 1);
-  char *cy_base = smem + wid * WAVE_BYTES;
-  char *cn_lane = cy_base + CY_BYTES + ((fl >> 1) - fl) * RC * 8 + (fl & 1) * 4;  // + aCY[d] -> CN slot
-  uint32_t *cbits = reinterpret_cast<uint32_t *>(smem + 4 * WAVE_BYTES);  // [256] per workgroup
-  cbits[threadIdx.x] = colbits[threadIdx.x];
-  __syncthreads();
-
-  const int n = p.n;
-  // byte offsets of this lane's D diagonals (row 0) and of its 16 owned columns
-  int aCY[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) aCY[d] = (fl * RC + diag_s[d * LPF + lam]) * 8;
-  const int col0 = fl * RC + lam;  // owned columns: lam + LPF c
-
-  const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
-  unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * FPW + fl;
-  bool active = frame < B;
-  bool need_load = true;
-  unsigned it = 0;
-  float R[K][D];
-
-  while (__any(active)) {
-    if (need_load && active) {  // per 16-lane group
-      float yv[CPL];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int j = lam + LPF * c;
-        yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
-      }
-      if (er_off != nullptr) {  // cyclic.h:259-262
-        for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
-          const int pos = er[e];
-#pragma unroll
-          for (int c = 0; c < CPL; ++c)
-            if (pos == lam + LPF * c) yv[c] = 0.0f;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, yv[c]);
-        *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
-      }
-      static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
-      it = 0;
-      need_load = false;
-    }
-
-    // ---------------- one min-sum iteration for the four resident frames ----------------
-#if CC_DIAG_PIPELINE
-    // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
-    // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
-    float2 cyq[D];
-    static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD]); });
-    static_for<K>([&](auto IR) {
-      constexpr int i = IR;
-      uint32_t m1[1], m2[1], sg[1];
-      {
-        float a1 = 0.0f, a2 = 0.0f;
-        uint32_t s = 0;
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
-          if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          const float q = e + cyq[d].y;                                       // :136,:207-209
-          R[i][d] = q;
-          const float a = __builtin_fabsf(q);
-          if constexpr (d == 0) {
-            a1 = a;
-            s = f2u(q);
-          } else if constexpr (d == 1) {
-            a2 = __builtin_fmaxf(a1, a);
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          } else {
-            a2 = __builtin_amdgcn_fmed3f(a1, a, a2);
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          }
-        });
-        m1[0] = f2u(a1);
-        m2[0] = f2u(a2);
-        sg[0] = s;
-      }
-      if constexpr (i + 1 < K)  // prefetch the next row's operands
-        static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD] + 8 * (i + 1)); });
-      float cn[D];
-      static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
-      row_allreduce<1, LPF>(m1, m2, sg);
-      const uint32_t sign31 = sg[0] & 0x80000000u;
-      if constexpr (VARIANT == CC_ALG_MS) {
-        const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          const uint32_t t = f2u(__builtin_amdgcn_fmed3f(__builtin_fabsf(R[i][d]), u2f(m1[0]), u2f(m2[0])));
-          R[i][d] = u2f(xad(t, Y, f2u(R[i][d]) & 0x80000000u));
-        });
-      } else {
-        const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[0]), p.alpha_f, p.beta_d));
-        const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[0]), p.alpha_f, p.beta_d));
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          const uint32_t mag = (__builtin_fabsf(R[i][d]) == u2f(m1[0])) ? H2 : H1;
-          R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
-        });
-      }
-      static_for<D>([&](auto DD) {
-        *reinterpret_cast<float *>(cn_lane + aCY[DD] + 8 * i) = cn[DD] + R[i][DD];  // ascending rows
-      });
-    });
-#else
-    static_for<K / RB>([&](auto RBI) {
-      constexpr int rb = RBI;
-      uint32_t m1[RB], m2[RB], sg[RB];
-      static_for<RB>([&](auto II) {
-        constexpr int ii = II, i = rb * RB + ii;
-        float a1 = kFltMax, a2 = kFltMax;
-        uint32_t s = 0;
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + aCY[d] + 8 * i);
-          float e = cy.x - R[i][d];                                           // soft_decision.h:135
-          if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          const float q = e + cy.y;                                           // :136,:207-209
-          R[i][d] = q;
-          const float a = __builtin_fabsf(q);
-          if constexpr (d == 0) {
-            a1 = a;
-            s = f2u(q);
-          } else if constexpr (d == 1) {  // sorted pair of the first two
-            a2 = __builtin_fmaxf(a1, a);
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          } else {
-            a2 = __builtin_amdgcn_fmed3f(a1, a, a2);  // insert into the sorted pair a1 <= a2
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          }
-        });
-        m1[ii] = f2u(a1);
-        m2[ii] = f2u(a2);
-        sg[ii] = s;
-      });
-      row_allreduce<RB, LPF>(m1, m2, sg);
-      static_for<RB>([&](auto II) {
-        constexpr int ii = II, i = rb * RB + ii;
-        const uint32_t sign31 = sg[ii] & 0x80000000u;  // parity of the row's negative messages (q is never -0.0f)
-        float cn[D];
-        static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
-        if constexpr (VARIANT == CC_ALG_MS) {
-          const uint32_t Y = (m1[ii] ^ m2[ii]) | sign31;
-          static_for<D>([&](auto DD) {
-            constexpr int d = DD;
-            const uint32_t t = f2u(__builtin_amdgcn_fmed3f(__builtin_fabsf(R[i][d]), u2f(m1[ii]), u2f(m2[ii])));
-            R[i][d] = u2f(xad(t, Y, f2u(R[i][d]) & 0x80000000u));
-          });
-        } else {
-          const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[ii]), p.alpha_f, p.beta_d));
-          const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[ii]), p.alpha_f, p.beta_d));
-          static_for<D>([&](auto DD) {
-            constexpr int d = DD;
-            const uint32_t mag = (__builtin_fabsf(R[i][d]) == u2f(m1[ii])) ? H2 : H1;
-            R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
-          });
-        }
-        static_for<D>([&](auto DD) {
-          *reinterpret_cast<float *>(cn_lane + aCY[DD] + 8 * i) = cn[DD] + R[i][DD];  // ascending rows
-        });
-      });
-    });
-
-#endif
-
-    // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
-    uint32_t pv = 0, any = 0;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const int j = lam + LPF * c;
-      const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
-      const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
-      const bool bit = (j < n) && (cnv + yc < 0.0f);  // L = cs + y :180-182, b = L < 0 codes.h:51
-      const uint32_t cb = cbits[j];
-      pv ^= bit ? cb : 0u;
-      any |= bit ? cb : 0u;
-      // next iteration: cs := cs', cs' := 0
-      *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
-      *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
-    }
-    bool ok;
-    if (p.stop_rule == CC_STOP_AS_SHIPPED)
-      ok = true;
-    else if (p.stop_rule == CC_STOP_PARITY)
-      ok = group_xor<LPF>(pv) == 0;
-    else
-      ok = group_or<LPF>(any) == 0;
-    const bool finished = ok || (it + 1 >= p.iterations);
-    if (finished && active) {
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int j = lam + LPF * c;
-        if (j < n) {
-          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
-          const float Lc = cy.x + cy.y;
-          hard[frame * n + j] = (Lc < 0.0f) ? 1 : 0;
-          if (Lout) Lout[frame * n + j] = Lc;
-        }
-      }
-      if (lam == 0) {
-        if (iters_out) iters_out[frame] = static_cast<uint16_t>(ok ? it : p.iterations);
-        if (status_out) status_out[frame] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
-      }
-      frame += ngroups;
-      active = frame < B;
-      need_load = true;
-    } else {
-      ++it;
-    }
-  }
-}
-
-}  // namespace
 
 // Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
 // in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
 static const DiagGeometry kDiagGeometries[] = {
     // n,   k,  w,  D, LPF, CPL
     {255, 24, 112, 7, 16, 16},  // BCH(255,231)
+    {255, 8, 128, 8, 16, 16},   // BCH(255,247)
+    {127, 7, 64, 8, 8, 16},     // BCH(127,120)
+    {127, 14, 56, 7, 8, 16},    // BCH(127,113)
+    {127, 21, 48, 6, 8, 16},    // BCH(127,106)
+    {63, 6, 32, 4, 8, 8},       // BCH(63,57)
     {63, 18, 24, 3, 8, 8},      // BCH(63,45)
+    {31, 5, 16, 2, 8, 4},       // BCH(31,26)
+    {31, 15, 8, 1, 8, 4},       // BCH(31,16)
+    {15, 4, 8, 1, 8, 2},        // BCH(15,11)
 };
 const DiagGeometry *diag_geometry(const CodeTables &t) {
   for (const DiagGeometry &g : kDiagGeometries)
@@ -473,57 +122,22 @@ size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
   return 4 * (fpw * rc * 8 + (fpw / 2) * rc * 8) + 256 * 4;
 }
 
-namespace {
-
-template <int K, int D, int LPF, int CPL, int OCC>
-int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
-                         const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
-                         size_t B, hipStream_t stream) {
-  constexpr int RB = (K % CC_DIAG_RB == 0) ? CC_DIAG_RB : 1;
-  constexpr int FPW = 64 / LPF;
-  const DiagGeometry g{0, 0, 0, D, LPF, CPL};
-  const size_t lds = minsum_diag_lds_bytes(g);
-  const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
-  unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
-  if (per_cu > static_cast<unsigned long long>(OCC)) per_cu = OCC;
-  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
-  const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
-  const unsigned long long Bq = B;
-  hipError_t e = hipSuccess;
-#define CC_LAUNCH(V)                                                                                                 \
-  {                                                                                                                  \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>),         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                      \
-    if (e == hipSuccess)                                                                                             \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>), dim3(grid), dim3(256), lds, stream, p,    \
-                         code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);  \
-  }                                                                                                                  \
-  break
-  switch (p.variant) {
-    case CC_ALG_MS: CC_LAUNCH(CC_ALG_MS);
-    case CC_ALG_NMS: CC_LAUNCH(CC_ALG_NMS);
-    case CC_ALG_OMS: CC_LAUNCH(CC_ALG_OMS);
-    case CC_ALG_2DNMS: CC_LAUNCH(CC_ALG_2DNMS);
-    default: e = hipErrorInvalidValue;
-  }
-#undef CC_LAUNCH
-  if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "minsum_diag kernel launch");
-  return CC_OK;
-}
-
-}  // namespace
 
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                        size_t B, hipStream_t stream) {
   const DiagGeometry *g = diag_geometry(code->tab);
   if (!g) return CC_ERR_UNSUPPORTED;
+  if (g->n <= 63)
+    return launch_minsum_diag_small(code, *g, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 #define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
   if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
   return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
   CC_GEO(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD
-  CC_GEO(18, 3, 8, 8, 4);    // BCH(63,45): 54 message registers, eight frames per wavefront
+  CC_GEO(8, 8, 16, 16, 3);   // BCH(255,247)
+  CC_GEO(7, 8, 8, 16, 3);    // BCH(127,120)
+  CC_GEO(14, 7, 8, 16, 2);   // BCH(127,113): 98 message registers
+  CC_GEO(21, 6, 8, 16, 2);   // BCH(127,106): 126 message registers
 #undef CC_GEO
   return CC_ERR_UNSUPPORTED;
 }
