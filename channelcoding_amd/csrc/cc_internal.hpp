@@ -98,6 +98,7 @@ int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d
 struct DiagGeometry {
   unsigned n, k, w;  // code length, rows of H, row weight
   int D, LPF, CPL;   // diagonals per lane, lanes per frame, columns per lane
+  bool scms;         // 2 K D registers fit: the self-correcting variants are instantiated too
 };
 const DiagGeometry *diag_geometry(const CodeTables &t);  // nullptr: no diagonal kernel for this code
 std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W);

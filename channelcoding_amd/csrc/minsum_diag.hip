@@ -8,17 +8,17 @@ namespace ccamd {
 // Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
 // in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
 static const DiagGeometry kDiagGeometries[] = {
-    // n,   k,  w,  D, LPF, CPL
-    {255, 24, 112, 7, 16, 16},  // BCH(255,231)
-    {255, 8, 128, 8, 16, 16},   // BCH(255,247)
-    {127, 7, 64, 8, 8, 16},     // BCH(127,120)
-    {127, 14, 56, 7, 8, 16},    // BCH(127,113)
-    {127, 21, 48, 6, 8, 16},    // BCH(127,106)
-    {63, 6, 32, 4, 8, 8},       // BCH(63,57)
-    {63, 18, 24, 3, 8, 8},      // BCH(63,45)
-    {31, 5, 16, 2, 8, 4},       // BCH(31,26)
-    {31, 15, 8, 1, 8, 4},       // BCH(31,16)
-    {15, 4, 8, 1, 8, 2},        // BCH(15,11)
+    // n,   k,  w,  D, LPF, CPL, SCMS1/2
+    {255, 24, 112, 7, 16, 16, false},  // BCH(255,231)
+    {255, 8, 128, 8, 16, 16, true},    // BCH(255,247)
+    {127, 7, 64, 8, 8, 16, true},      // BCH(127,120)
+    {127, 14, 56, 7, 8, 16, false},    // BCH(127,113)
+    {127, 21, 48, 6, 8, 16, false},    // BCH(127,106)
+    {63, 6, 32, 4, 8, 8, true},        // BCH(63,57)
+    {63, 18, 24, 3, 8, 8, true},       // BCH(63,45)
+    {31, 5, 16, 2, 8, 4, true},        // BCH(31,26)
+    {31, 15, 8, 1, 8, 4, true},        // BCH(31,16)
+    {15, 4, 8, 1, 8, 2, true},         // BCH(15,11)
 };
 const DiagGeometry *diag_geometry(const CodeTables &t) {
   for (const DiagGeometry &g : kDiagGeometries)
@@ -96,6 +96,9 @@ bool minsum_diag_supported(const cc_code *code) {
   }();
   if (disabled || code->d_diag == nullptr || code->desc.iterations == 0) return false;
   const int alg = code->desc.algorithm;
+  const DiagGeometry *geo = diag_geometry(code->tab);
+  if (!geo) return false;
+  if (alg == CC_ALG_SCMS1 || alg == CC_ALG_SCMS2) return geo->scms;
   if (alg != CC_ALG_MS && alg != CC_ALG_NMS && alg != CC_ALG_OMS && alg != CC_ALG_2DNMS) return false;
   if (alg == CC_ALG_OMS && !(code->desc.beta >= 0.0)) return false;
   const float a = static_cast<float>(code->desc.alpha);
@@ -133,12 +136,16 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
 #define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
   if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
   return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
+#define CC_GEO_S(KK, DD, LL, CC, OO)                                                                            \
+  if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
+  return launch_diag_geometry<KK, DD, LL, CC, OO, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
   CC_GEO(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD
-  CC_GEO(8, 8, 16, 16, 3);   // BCH(255,247)
-  CC_GEO(7, 8, 8, 16, 3);    // BCH(127,120)
+  CC_GEO_S(8, 8, 16, 16, 3);  // BCH(255,247), self-correcting variants included (128 message registers)
+  CC_GEO_S(7, 8, 8, 16, 3);   // BCH(127,120)
   CC_GEO(14, 7, 8, 16, 2);   // BCH(127,113): 98 message registers
   CC_GEO(21, 6, 8, 16, 2);   // BCH(127,106): 126 message registers
 #undef CC_GEO
+#undef CC_GEO_S
   return CC_ERR_UNSUPPORTED;
 }
 

@@ -114,6 +114,18 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return LPF == 16 ? or_stage<0x140>(v) : v;
 }
 
+__device__ __forceinline__ int signum(float v) { return (0.0f < v) - (v < 0.0f); }
+// variable-node functor of the self-correcting variants: q = fn(e + y, q_old)
+template <int VARIANT>
+__device__ __forceinline__ float self_correct(float tmp, float q_old) {
+  if constexpr (VARIANT == CC_ALG_SCMS1) {  // soft_decision.h:261-266
+    const int so = signum(q_old);
+    return (so == 0 || so == signum(tmp)) ? tmp : 0.0f;
+  } else {  // SCMS2, :275-280
+    return (tmp * q_old > 0.0f) ? tmp : 0.5f * (tmp + q_old);
+  }
+}
+
 template <int VARIANT>
 __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_d) {
   if constexpr (VARIANT == CC_ALG_NMS || VARIANT == CC_ALG_2DNMS) {
@@ -165,6 +177,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   bool need_load = true;
   unsigned it = 0;
   float R[K][D];
+  // self-correcting variants keep the previous variable->check message of every edge as well (instantiated
+  // only where 2 K D registers fit, see kDiagGeometries)
+  constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
+  float Q[NEEDQ ? K : 1][NEEDQ ? D : 1];
 
   while (__any(active)) {
     if (need_load && active) {  // per 16-lane group
@@ -188,6 +204,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
       }
       static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+      if constexpr (NEEDQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
       it = 0;
       need_load = false;
     }
@@ -210,7 +227,11 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           constexpr int d = DD;
           float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
           if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          const float q = e + cyq[d].y;                                       // :136,:207-209
+          float q = e + cyq[d].y;                                             // :136,:207-209
+          if constexpr (NEEDQ) {
+            q = self_correct<VARIANT>(q, Q[i][d]);
+            Q[i][d] = q;
+          }
           R[i][d] = q;
           const float a = __builtin_fabsf(q);
           if constexpr (d == 0) {
@@ -274,7 +295,11 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           const float2 cy = *reinterpret_cast<const float2 *>(cy_base + aCY[d] + 8 * i);
           float e = cy.x - R[i][d];                                           // soft_decision.h:135
           if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          const float q = e + cy.y;                                           // :136,:207-209
+          float q = e + cy.y;                                                 // :136,:207-209
+          if constexpr (NEEDQ) {
+            q = self_correct<VARIANT>(q, Q[i][d]);
+            Q[i][d] = q;
+          }
           R[i][d] = q;
           const float a = __builtin_fabsf(q);
           if constexpr (d == 0) {
@@ -380,35 +405,44 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 namespace {
 
-template <int K, int D, int LPF, int CPL, int OCC>
+template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false>
 int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
   constexpr int RB = (K % CC_DIAG_RB == 0) ? CC_DIAG_RB : 1;
   constexpr int FPW = 64 / LPF;
-  const DiagGeometry g{0, 0, 0, D, LPF, CPL};
+  const DiagGeometry g{0, 0, 0, D, LPF, CPL, SCMS};
   const size_t lds = minsum_diag_lds_bytes(g);
   const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
   unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
-  if (per_cu > static_cast<unsigned long long>(OCC)) per_cu = OCC;
+  const bool scms_variant = p.variant == CC_ALG_SCMS1 || p.variant == CC_ALG_SCMS2;
+  const unsigned long long occ = scms_variant ? ((2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : 2) : OCC;
+  if (per_cu > occ) per_cu = occ;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
-#define CC_LAUNCH(V)                                                                                                 \
-  {                                                                                                                  \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>),         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                      \
-    if (e == hipSuccess)                                                                                             \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, OCC>), dim3(grid), dim3(256), lds, stream, p,    \
-                         code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);  \
-  }                                                                                                                  \
-  break
+  // the self-correcting variants carry K D more registers per lane: their own occupancy target
+  constexpr int OCC_S = (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : 2;
+#define CC_LAUNCH(V, O)                                                                                            \
+  {                                                                                                                \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O>),         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                    \
+    if (e == hipSuccess)                                                                                           \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O>), dim3(grid), dim3(256), lds, stream, p,    \
+                         code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);\
+  }
   switch (p.variant) {
-    case CC_ALG_MS: CC_LAUNCH(CC_ALG_MS);
-    case CC_ALG_NMS: CC_LAUNCH(CC_ALG_NMS);
-    case CC_ALG_OMS: CC_LAUNCH(CC_ALG_OMS);
-    case CC_ALG_2DNMS: CC_LAUNCH(CC_ALG_2DNMS);
+    case CC_ALG_MS: CC_LAUNCH(CC_ALG_MS, OCC) break;
+    case CC_ALG_NMS: CC_LAUNCH(CC_ALG_NMS, OCC) break;
+    case CC_ALG_OMS: CC_LAUNCH(CC_ALG_OMS, OCC) break;
+    case CC_ALG_2DNMS: CC_LAUNCH(CC_ALG_2DNMS, OCC) break;
+    case CC_ALG_SCMS1:
+      if constexpr (SCMS) CC_LAUNCH(CC_ALG_SCMS1, OCC_S) else e = hipErrorInvalidValue;
+      break;
+    case CC_ALG_SCMS2:
+      if constexpr (SCMS) CC_LAUNCH(CC_ALG_SCMS2, OCC_S) else e = hipErrorInvalidValue;
+      break;
     default: e = hipErrorInvalidValue;
   }
 #undef CC_LAUNCH

@@ -9,9 +9,9 @@ int launch_minsum_diag_small(const cc_code *code, const DiagGeometry &g, const M
                              uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
 #define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
   if (g.k == KK && g.D == DD && g.LPF == LL && g.CPL == CC)                                                     \
-  return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
+  return launch_diag_geometry<KK, DD, LL, CC, OO, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
   CC_GEO(6, 4, 8, 8, 4);   // BCH(63,57)
-  CC_GEO(18, 3, 8, 8, 4);  // BCH(63,45): 54 message registers
+  CC_GEO(18, 3, 8, 8, 4);  // BCH(63,45): 54 message registers (108 with the self-correcting variants' q)
   CC_GEO(5, 2, 8, 4, 4);   // BCH(31,26)
   CC_GEO(15, 1, 8, 4, 4);  // BCH(31,16)
   CC_GEO(4, 1, 8, 2, 4);   // BCH(15,11)
