@@ -8,17 +8,26 @@ namespace ccamd {
 // Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
 // in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
 static const DiagGeometry kDiagGeometries[] = {
-    // n,   k,  w,  D, LPF, CPL, SCMS1/2
-    {255, 24, 112, 7, 16, 16, false},  // BCH(255,231)
+    // n,   k,  w,  D, LPF, CPL, SCMS1/2     (w < LPF * D: the last slot of some lanes is empty, "partial")
+    {255, 24, 112, 7, 16, 16, true},   // BCH(255,231)
+    {255, 16, 120, 8, 16, 16, true},  // BCH(255,239), partial
+    {255, 32, 124, 8, 16, 16, false}, // BCH(255,223), partial; one wave per SIMD
     {255, 8, 128, 8, 16, 16, true},    // BCH(255,247)
     {127, 7, 64, 8, 8, 16, true},      // BCH(127,120)
-    {127, 14, 56, 7, 8, 16, false},    // BCH(127,113)
-    {127, 21, 48, 6, 8, 16, false},    // BCH(127,106)
+    {127, 14, 56, 7, 8, 16, true},    // BCH(127,113)
+    {127, 21, 48, 6, 8, 16, true},    // BCH(127,106)
+    {127, 28, 56, 7, 8, 16, false},   // BCH(127,99): one wave per SIMD, part of the messages in AGPRs
     {63, 6, 32, 4, 8, 8, true},        // BCH(63,57)
+    {63, 12, 28, 4, 8, 8, true},       // BCH(63,51), partial
     {63, 18, 24, 3, 8, 8, true},       // BCH(63,45)
+    {63, 24, 28, 4, 8, 8, true},      // BCH(63,39), partial
     {31, 5, 16, 2, 8, 4, true},        // BCH(31,26)
+    {31, 10, 12, 2, 8, 4, true},       // BCH(31,21), partial
     {31, 15, 8, 1, 8, 4, true},        // BCH(31,16)
+    {31, 20, 6, 1, 8, 4, true},        // BCH(31,11), partial
     {15, 4, 8, 1, 8, 2, true},         // BCH(15,11)
+    {15, 8, 4, 1, 8, 2, true},         // BCH(15,7), partial
+    {15, 10, 4, 1, 8, 2, true},        // BCH(15,5), partial
 };
 const DiagGeometry *diag_geometry(const CodeTables &t) {
   for (const DiagGeometry &g : kDiagGeometries)
@@ -41,7 +50,7 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
       else
         left.push_back(cls[r][e]);
     }
-  for (int g = D - 1; g >= 0; --g) {  // fill holes, preferring residues not yet doubled in the group
+  for (int g = 0; g < D; ++g) {  // fill holes, preferring residues not yet doubled in the group
     while (grp[g].size() < static_cast<size_t>(W) && !left.empty()) {
       size_t best = 0;
       int best_mult = 1 << 30;
@@ -57,6 +66,13 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
       left.erase(left.begin() + static_cast<long>(best));
     }
   }
+  // w < W * D: only the last slot may stay short -- top the others up from it, pad it with the marker 0xFFFF
+  for (int g = 0; g + 1 < D; ++g)
+    while (grp[g].size() < static_cast<size_t>(W) && !grp[D - 1].empty()) {
+      grp[g].push_back(grp[D - 1].back());
+      grp[D - 1].pop_back();
+    }
+  const size_t real_last = grp[D - 1].size();
   // local search: swap elements between groups while the total bank multiplicity (sum over slots of the
   // largest number of lanes on one residue class -- the LDS passes a slot instruction needs) decreases
   auto group_cost = [&](const std::vector<unsigned> &g) {
@@ -73,8 +89,8 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
     improved = false;
     for (int a = 0; a < D && !improved; ++a)
       for (int b = a + 1; b < D && !improved; ++b)
-        for (int x = 0; x < W && !improved; ++x)
-          for (int y = 0; y < W && !improved; ++y) {
+        for (size_t x = 0; x < grp[a].size() && !improved; ++x)
+          for (size_t y = 0; y < grp[b].size() && !improved; ++y) {
             const int before = group_cost(grp[a]) + group_cost(grp[b]);
             std::swap(grp[a][x], grp[b][y]);
             if (group_cost(grp[a]) + group_cost(grp[b]) < before)
@@ -83,9 +99,10 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
               std::swap(grp[a][x], grp[b][y]);
           }
   }
-  std::vector<uint16_t> out(static_cast<size_t>(D) * W, 0);
+  std::vector<uint16_t> out(static_cast<size_t>(D) * W, 0xFFFFu);
   for (int g = 0; g < D; ++g)
-    for (int l = 0; l < W; ++l) out[g * W + l] = static_cast<uint16_t>(grp[g][l]);
+    for (size_t l = 0; l < grp[g].size(); ++l) out[g * W + l] = static_cast<uint16_t>(grp[g][l]);
+  (void)real_last;
   return out;
 }
 
@@ -106,22 +123,17 @@ bool minsum_diag_supported(const cc_code *code) {
   return diag_geometry(code->tab) != nullptr;
 }
 
-#ifndef CC_DIAG_PIPELINE
-#define CC_DIAG_PIPELINE 1
-#endif
-#ifndef CC_DIAG_RB
-#define CC_DIAG_RB 2
-#endif
 
 std::string minsum_diag_name(const cc_code *code) {
   const DiagGeometry *g = diag_geometry(code->tab);
   if (!g) return "minsum_diag_kernel";
   return "minsum_diag_kernel<K=" + std::to_string(g->k) + ",D=" + std::to_string(g->D) + ",LPF=" +
-         std::to_string(g->LPF) + (CC_DIAG_PIPELINE ? ",row-pipelined>" : ">");
+         std::to_string(g->LPF) + ",row-pipelined>";
 }
 
 size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
-  const size_t fpw = 64 / g.LPF, rc = static_cast<size_t>(g.LPF) * g.CPL + 16;
+  const bool partial = g.w != static_cast<unsigned>(g.LPF * g.D);
+  const size_t fpw = 64 / g.LPF, rc = static_cast<size_t>(g.LPF) * g.CPL + (partial ? 48 : 16);
   return 4 * (fpw * rc * 8 + (fpw / 2) * rc * 8) + 256 * 4;
 }
 
@@ -139,11 +151,21 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
 #define CC_GEO_S(KK, DD, LL, CC, OO)                                                                            \
   if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
   return launch_diag_geometry<KK, DD, LL, CC, OO, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
-  CC_GEO(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD
+  if (g->w != static_cast<unsigned>(g->LPF * g->D)) {  // partial geometries
+    if (g->k == 16 && g->D == 8 && g->LPF == 16)
+      return launch_diag_geometry<16, 8, 16, 16, 2, true, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,
+                                                                 d_status, B, stream);  // BCH(255,239)
+    if (g->k == 32 && g->D == 8 && g->LPF == 16)
+      return launch_diag_geometry<32, 8, 16, 16, 1, false, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,
+                                                                 d_status, B, stream);  // BCH(255,223)
+    return CC_ERR_UNSUPPORTED;
+  }
+  CC_GEO_S(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD (one for SCMS1/2)
   CC_GEO_S(8, 8, 16, 16, 3);  // BCH(255,247), self-correcting variants included (128 message registers)
   CC_GEO_S(7, 8, 8, 16, 3);   // BCH(127,120)
-  CC_GEO(14, 7, 8, 16, 2);   // BCH(127,113): 98 message registers
-  CC_GEO(21, 6, 8, 16, 2);   // BCH(127,106): 126 message registers
+  CC_GEO_S(14, 7, 8, 16, 2);  // BCH(127,113): 98 message registers
+  CC_GEO_S(21, 6, 8, 16, 2);  // BCH(127,106): 126 message registers
+  CC_GEO(28, 7, 8, 16, 1);    // BCH(127,99): 196 message registers
 #undef CC_GEO
 #undef CC_GEO_S
   return CC_ERR_UNSUPPORTED;

@@ -31,9 +31,6 @@
 #include "cc_internal.hpp"
 #include "wave_ops.hpp"
 
-#ifndef CC_DIAG_PIPELINE
-#define CC_DIAG_PIPELINE 1
-#endif
 
 namespace ccamd {
 namespace {
@@ -140,7 +137,7 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
 
 // K rows, D diagonals per lane (LPF * D = row weight), RB rows per reduction batch, LPF lanes per frame (64 / LPF
 // frames per wavefront), CPL columns per lane (LPF * CPL >= n), OCC = waves per SIMD the register budget targets
-template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC>
+template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL>
 __global__ void __launch_bounds__(256, OCC)
 minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
                    const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
@@ -149,7 +146,9 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   static_assert(K % RB == 0 && K <= 32, "row batching");
   static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
   constexpr int FPW = 64 / LPF;          // frames per wavefront
-  constexpr int RC = LPF * CPL + 16;     // columns of one frame's LDS region (+16 pad: odd frames start 16 banks later)
+  // columns of one frame's LDS region: + 16 pad (odd frames start 16 banks later); PARTIAL geometries (row weight
+  // not a multiple of LPF) append 32 scratch columns that absorb the accesses of the lanes whose last slot is empty
+  constexpr int RC = LPF * CPL + (PARTIAL ? 48 : 16);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // CY: one float2 {cs, y} per column, frame f at f * RC.  CN: one float per column at an 8-byte
   // stride, the two frames of a 32-lane half interleaved on even / odd dwords (conflict-free, and the byte
@@ -169,6 +168,18 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   int aCY[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) aCY[d] = (fl * RC + diag_s[d * LPF + lam]) * 8;
+  // PARTIAL: slot D - 1 of some lanes holds no diagonal (marker 0xFFFF).  Such a lane runs the same instructions
+  // on the frame's scratch columns; its magnitude is replaced by numeric_limits<float>::max() (neutral for the
+  // minima, NaN-proof: v_max returns the other operand), its sign bit is masked out of the row parity.
+  float pen = 0.0f;
+  uint32_t sgn_keep = 0xFFFFFFFFu;
+  if constexpr (PARTIAL) {
+    if (diag_s[(D - 1) * LPF + lam] == 0xFFFFu) {
+      aCY[D - 1] = (fl * RC + LPF * CPL + 16) * 8;
+      pen = 3.402823466e+38f;
+      sgn_keep = 0u;
+    }
+  }
   const int col0 = fl * RC + lam;  // owned columns: lam + LPF c
 
   const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
@@ -210,7 +221,6 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     }
 
     // ---------------- one min-sum iteration for the four resident frames ----------------
-#if CC_DIAG_PIPELINE
     // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
     // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
     float2 cyq[D];
@@ -233,14 +243,19 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             Q[i][d] = q;
           }
           R[i][d] = q;
-          const float a = __builtin_fabsf(q);
+          float a = __builtin_fabsf(q);
+          uint32_t qb = f2u(q);
+          if constexpr (PARTIAL && d == D - 1) {
+            a = __builtin_fmaxf(a, pen);
+            qb &= sgn_keep;
+          }
           if constexpr (d == 0) {
             a1 = a;
-            s = f2u(q);
+            s = qb;
           } else if constexpr (d == 1) {
             a2 = __builtin_fmaxf(a1, a);
             a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
+            s ^= qb;
           } else {
             a2 = __builtin_amdgcn_fmed3f(a1, a, a2);
             a1 = __builtin_fminf(a1, a);
@@ -282,73 +297,6 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       // above this row's write (it did for D = 1, where nothing else sits between them).
       asm volatile("" ::: "memory");
     });
-#else
-    static_for<K / RB>([&](auto RBI) {
-      constexpr int rb = RBI;
-      uint32_t m1[RB], m2[RB], sg[RB];
-      static_for<RB>([&](auto II) {
-        constexpr int ii = II, i = rb * RB + ii;
-        float a1 = 3.402823466e+38f, a2 = 3.402823466e+38f;
-        uint32_t s = 0;
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + aCY[d] + 8 * i);
-          float e = cy.x - R[i][d];                                           // soft_decision.h:135
-          if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          float q = e + cy.y;                                                 // :136,:207-209
-          if constexpr (NEEDQ) {
-            q = self_correct<VARIANT>(q, Q[i][d]);
-            Q[i][d] = q;
-          }
-          R[i][d] = q;
-          const float a = __builtin_fabsf(q);
-          if constexpr (d == 0) {
-            a1 = a;
-            s = f2u(q);
-          } else if constexpr (d == 1) {  // sorted pair of the first two
-            a2 = __builtin_fmaxf(a1, a);
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          } else {
-            a2 = __builtin_amdgcn_fmed3f(a1, a, a2);  // insert into the sorted pair a1 <= a2
-            a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
-          }
-        });
-        m1[ii] = f2u(a1);
-        m2[ii] = f2u(a2);
-        sg[ii] = s;
-      });
-      row_allreduce<RB, LPF>(m1, m2, sg);
-      static_for<RB>([&](auto II) {
-        constexpr int ii = II, i = rb * RB + ii;
-        const uint32_t sign31 = sg[ii] & 0x80000000u;  // parity of the row's negative messages (q is never -0.0f)
-        float cn[D];
-        static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
-        if constexpr (VARIANT == CC_ALG_MS) {
-          const uint32_t Y = (m1[ii] ^ m2[ii]) | sign31;
-          static_for<D>([&](auto DD) {
-            constexpr int d = DD;
-            const uint32_t t = f2u(__builtin_amdgcn_fmed3f(__builtin_fabsf(R[i][d]), u2f(m1[ii]), u2f(m2[ii])));
-            R[i][d] = u2f(xad(t, Y, f2u(R[i][d]) & 0x80000000u));
-          });
-        } else {
-          const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[ii]), p.alpha_f, p.beta_d));
-          const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[ii]), p.alpha_f, p.beta_d));
-          static_for<D>([&](auto DD) {
-            constexpr int d = DD;
-            const uint32_t mag = (__builtin_fabsf(R[i][d]) == u2f(m1[ii])) ? H2 : H1;
-            R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
-          });
-        }
-        static_for<D>([&](auto DD) {
-          *reinterpret_cast<float *>(cn_lane + aCY[DD] + 8 * i) = cn[DD] + R[i][DD];  // ascending rows
-        });
-        asm volatile("" ::: "memory");  // see the pipelined variant: cross-lane read-after-write through LDS
-      });
-    });
-
-#endif
 
     // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
     uint32_t pv = 0, any = 0;
@@ -399,37 +347,34 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 }  // namespace
 
-#ifndef CC_DIAG_RB
-#define CC_DIAG_RB 2
-#endif
-
 namespace {
 
-template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false>
+template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false>
 int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
-  constexpr int RB = (K % CC_DIAG_RB == 0) ? CC_DIAG_RB : 1;
+  constexpr int RB = 1;  // rows per reduction batch (the row-pipelined body reduces one row at a time)
+  // the self-correcting variants carry K D more registers per lane: their own occupancy target (beyond 256
+  // registers a single wave per SIMD spills q to the accumulation registers: still far ahead of the generic kernel)
+  constexpr int OCC_S = (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : (2 * K * D + 64 <= 256) ? 2 : 1;
   constexpr int FPW = 64 / LPF;
-  const DiagGeometry g{0, 0, 0, D, LPF, CPL, SCMS};
+  const DiagGeometry g{0, 0, PARTIAL ? 1u : static_cast<unsigned>(LPF * D), D, LPF, CPL, SCMS};
   const size_t lds = minsum_diag_lds_bytes(g);
   const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
   unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
   const bool scms_variant = p.variant == CC_ALG_SCMS1 || p.variant == CC_ALG_SCMS2;
-  const unsigned long long occ = scms_variant ? ((2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : 2) : OCC;
+  const unsigned long long occ = scms_variant ? static_cast<unsigned long long>(OCC_S) : OCC;
   if (per_cu > occ) per_cu = occ;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
-  // the self-correcting variants carry K D more registers per lane: their own occupancy target
-  constexpr int OCC_S = (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : 2;
 #define CC_LAUNCH(V, O)                                                                                            \
   {                                                                                                                \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O>),         \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL>),         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                    \
     if (e == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O>), dim3(grid), dim3(256), lds, stream, p,    \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL>), dim3(grid), dim3(256), lds, stream, p,    \
                          code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);\
   }
   switch (p.variant) {
