@@ -294,3 +294,25 @@ def test_minsum_extreme_code_parameters(q, t):
     for ov, alpha, beta, rule in ((0, 1.0, 0.0, O2), (1, 0.8, 0.0, O2), (3, 1.0, 0.0, O2), (2, 1.0, 0.01, O1)):
         code = cc.primitive_bch(q, cc.errors(t), TAG[ov](10, alpha, beta), stop_rule=rule)
         check(code.correct_batch(y, want_L=True), *o.minsum(ov, 10, y, alpha, beta, rule, fast=True), tag=(q, t, ov))
+
+
+@pytest.mark.parametrize("env,expect", [({"CC_AMD_NO_DIAG": "1"}, "minsum_reg_kernel"),
+                                        ({"CC_AMD_FORCE_GENERIC": "1"}, "minsum_generic_kernel")])
+def test_fallback_kernels_stay_exact(env, expect):
+    """The diagonal kernel now covers every code the register-resident kernel was written for, and both shadow
+    the generic kernel: run the seeded oracle comparison again in a child process with the dispatch overrides
+    (read once per process) so the two fallbacks keep their parity coverage."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = ("import channelcoding_amd as cc; "
+             "print(cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(5)).kernel_info()['kernel'])")
+    child_env = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=child_env, cwd=root)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith(expect), out.stdout + out.stderr
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "tests/test_gpu_minsum.py::test_minsum_vs_oracle_seeded",
+                          "tests/test_gpu_minsum.py::test_minsum_golden"],
+                         capture_output=True, text=True, env=child_env, cwd=root, timeout=900)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-1000:]
