@@ -124,6 +124,7 @@ int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t
 // encode.hip
 std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t);
 int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
+int launch_encode_bits(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
 int launch_extract(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, hipStream_t stream);
 // mc.hip (Monte-Carlo calls on one handle must be issued on one stream at a time: they share a workspace)
 int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames, int random_codewords,

@@ -70,6 +70,42 @@ encode_division_kernel(const AlgebraicTables *__restrict__ T, const uint8_t *__r
   }
 }
 
+// Binary BCH, message symbols known to be 0 / 1 (the Monte-Carlo source), at most 32 parity bits: the k parity
+// bits of a frame are one 32-bit word, the XOR of the words P[j] = bits of x^(k+j) mod g over the set message
+// bits.  Lane l keeps P for its four message positions in registers: four masked XORs and one wave reduction per
+// frame instead of k GF multiply-accumulate passes.
+__global__ void __launch_bounds__(256)
+encode_bch_bits_kernel(const uint8_t *__restrict__ PT, const uint8_t *__restrict__ msg, uint8_t *__restrict__ cw, int n,
+                       int k, int l, unsigned long long B) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t P[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = lane + 64 * c;
+    P[c] = 0;
+    if (j < l)
+      for (int i = 0; i < k; ++i) P[c] |= static_cast<uint32_t>(PT[i * l + j] & 1u) << i;
+  }
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+    uint32_t b[4], acc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      b[c] = j < l ? (msg[f * l + j] & 1u) : 0u;
+      acc ^= P[c] & (0u - b[c]);
+    }
+    acc = __builtin_amdgcn_readlane(wave_xor(acc), 63);
+    if (lane < k) cw[f * n + lane] = static_cast<uint8_t>((acc >> lane) & 1u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      if (j < l) cw[f * n + k + j] = static_cast<uint8_t>(b[c]);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 encode_multiplication_kernel(const AlgebraicTables *__restrict__ T, const uint8_t *__restrict__ msg,
                              uint8_t *__restrict__ cw, unsigned long long B) {
@@ -207,6 +243,23 @@ int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size
     hipLaunchKernelGGL(encode_division_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, code->d_parity, d_msg,
                        d_cw, Bq);
   }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "encode kernel launch");
+  return CC_OK;
+}
+
+// systematic encode of 0 / 1 message symbols (callers guarantee the symbol range: the Monte-Carlo source)
+int launch_encode_bits(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  if (code->tab.family != CC_FAMILY_BCH || code->desc.coding != CC_CODING_DIVISION || code->tab.k > 32 ||
+      code->d_parity == nullptr)
+    return launch_encode(code, d_msg, d_cw, B, stream);
+  const unsigned long long blocks_needed = (B + 3) / 4;
+  const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
+  const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
+  hipLaunchKernelGGL(encode_bch_bits_kernel, dim3(grid), dim3(256), 0, stream, code->d_parity, d_msg, d_cw,
+                     static_cast<int>(code->tab.n), static_cast<int>(code->tab.k), static_cast<int>(code->tab.l),
+                     static_cast<unsigned long long>(B));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "encode kernel launch");
   return CC_OK;

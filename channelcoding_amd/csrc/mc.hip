@@ -218,7 +218,7 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
     hipLaunchKernelGGL(random_bits_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_msg_scratch, l,
                        bits_log2, static_cast<unsigned long long>(first_frame),
                        static_cast<unsigned long long>(frames), k0, k1);
-    const int rc = launch_encode(code, d_msg_scratch, d_sent, frames, stream);
+    const int rc = launch_encode_bits(code, d_msg_scratch, d_sent, frames, stream);
     if (rc != CC_OK) return rc;
     sent = d_sent;
   } else if (d_sent) {
