@@ -81,9 +81,9 @@ typedef enum cc_stop_rule {
 typedef struct cc_desc {
   uint32_t struct_size; /* = sizeof(cc_desc)                                                   */
   int32_t family;       /* cc_family                                                           */
-  uint32_t q;           /* GF(2^q), 2..8; default modular polynomials of galois.h:18-20        */
+  uint32_t q;           /* GF(2^q), 3..8; default modular polynomials of galois.h:18-20        */
   uint32_t t;           /* errors<t>; for dmin<d> pass (d-1)/2 (codes.h:14-26)                 */
-  uint32_t n;           /* 0 or 2^q-1 (shortened codes are not supported yet)                  */
+  uint32_t n;           /* 0 or 2^q-1 (the reference's N is a TODO there too, cyclic.h:66)     */
   uint32_t mu, step;    /* RS only: roots alpha^(mu + i*step), rs.h:18-39; use 1, 1            */
   int32_t coding;       /* cc_coding                                                           */
   int32_t algorithm;    /* cc_algorithm                                                        */
