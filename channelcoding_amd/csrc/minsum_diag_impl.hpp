@@ -193,6 +193,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
   float Q[NEEDQ ? K : 1][NEEDQ ? D : 1];
 
+  float pf_sink = 0.0f;
   while (__any(active)) {
     if (need_load && active) {  // per 16-lane group
       float yv[CPL];
@@ -200,6 +201,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       for (int c = 0; c < CPL; ++c) {
         const int j = lam + LPF * c;
         yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
+      }
+      // touch the frame this group decodes next: one load per 64-byte line brings it into L2 while the current
+      // frame iterates.  The data is never used; its destination is a register dedicated to that for the whole
+      // kernel (read-write asm operand, consumed after the main loop), so a late write-back cannot hit a live value
+      if (frame + ngroups < B) {
+        const float *nxt = llr + (frame + ngroups) * n;
+#pragma unroll
+        for (int c = 0; c < (LPF * CPL + 16 * LPF - 1) / (16 * LPF); ++c) {
+          const int j = 16 * (lam + LPF * c);  // one load per 64-byte line
+          if (j < n) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(nxt + j) : "memory");
+        }
       }
       if (er_off != nullptr) {  // cyclic.h:259-262
         for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
@@ -343,6 +355,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       ++it;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");  // the sink register stays reserved until here
 }
 
 }  // namespace
