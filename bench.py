@@ -165,6 +165,17 @@ print(time.perf_counter() - t0)
 """
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(y_sample, iterations, budget_s=12.0):
     """Reference CPU path on this box's host cores, same frames as the GPU workload, stop rule O2.  The reference
     decodes one frame at a time on one thread (src/simulation/simulation.c++:124-136) and gets its parallelism from
@@ -196,7 +207,7 @@ def cpu_baseline(y_sample, iterations, budget_s=12.0):
     sec = max(secs)
     return dict(value=cores * m / sec, unit="frames/s", cores=cores, kind=kind, per_core=m / (sum(secs) / cores),
                 sample="%d processes x %d of the benchmark's frames, slowest %.1f s, %s" % (cores, m, sec, what),
-                host_cpus=os.cpu_count())
+                host_cpus=os.cpu_count(), cpu_model=cpu_model())
 
 
 def main():
