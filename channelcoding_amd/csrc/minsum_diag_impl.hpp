@@ -160,6 +160,9 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   char *cy_base = smem + wid * WAVE_BYTES;
   char *cn_lane = cy_base + CY_BYTES + ((fl >> 1) - fl) * RC * 8 + (fl & 1) * 4;  // + aCY[d] -> CN slot
   uint32_t *cbits = reinterpret_cast<uint32_t *>(smem + 4 * WAVE_BYTES);  // [256] per workgroup
+  // 256 bytes per wavefront that absorb the look-ahead loads (see the load block)
+  const uint32_t lds_sink = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<size_t>(smem + 4 * WAVE_BYTES + 1024 + wid * 256)));
   cbits[threadIdx.x] = colbits[threadIdx.x];
   __syncthreads();
 
@@ -193,7 +196,6 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
   float Q[NEEDQ ? K : 1][NEEDQ ? D : 1];
 
-  float pf_sink = 0.0f;
   while (__any(active)) {
     if (need_load && active) {  // per 16-lane group
       float yv[CPL];
@@ -202,15 +204,20 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         const int j = lam + LPF * c;
         yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
       }
-      // touch the frame this group decodes next: one load per 64-byte line brings it into L2 while the current
-      // frame iterates.  The data is never used; its destination is a register dedicated to that for the whole
-      // kernel (read-write asm operand, consumed after the main loop), so a late write-back cannot hit a live value
+      // Touch the frame this group decodes next: one load per 64-byte line brings it into L2 while the current
+      // frame iterates.  The data is never used, so it must not land in a VGPR the allocator may hand to a live
+      // value before the load returns: global_load_lds writes it to a scratch line of LDS instead (M0 = LDS
+      // address, saved and restored inside the block).
       if (frame + ngroups < B) {
         const float *nxt = llr + (frame + ngroups) * n;
 #pragma unroll
         for (int c = 0; c < (LPF * CPL + 16 * LPF - 1) / (16 * LPF); ++c) {
           const int j = 16 * (lam + LPF * c);  // one load per 64-byte line
-          if (j < n) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(nxt + j) : "memory");
+          if (j < n) {
+            uint32_t m0_save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_save) : "v"(nxt + j), "s"(lds_sink) : "memory");
+          }
         }
       }
       if (er_off != nullptr) {  // cyclic.h:259-262
@@ -355,7 +362,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       ++it;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");  // the sink register stays reserved until here
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS write-back may outlive the workgroup's allocation
 }
 
 }  // namespace
