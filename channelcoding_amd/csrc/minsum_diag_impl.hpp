@@ -1,5 +1,6 @@
-// minsum_diag.hip -- diagonal-parallel min-sum kernel: 16 lanes per codeword, four codewords per
-// wavefront, every (lane, slot, row) triple is a real edge of H.
+// minsum_diag_impl.hpp -- diagonal-parallel min-sum kernel: 16 (or 8) lanes per codeword, four (eight) codewords
+// per wavefront, every (lane, slot, row) triple is a real edge of H.  The text below describes the BCH(255,231)
+// instantiation; the template parameters generalise it (see minsum_diag.hip).
 //
 // Why (measured on MI355X, profiles/r01_ubench_instruction_rates.txt): only f32 add/sub/mul issue at
 // ~2.5 cycles per wave instruction; every other VALU op (min/max/med3, integer, compare, select, DPP)
@@ -17,8 +18,10 @@
 //                           row order -- the reference's summation order (soft_decision.h:88-95).
 //     Within one row all 112 diagonals hit distinct columns, successive rows are ordered by program
 //     order (LDS operations of a wave execute in order), so no atomics are needed.
-//   * 16-lane groups are persistent: a group that converged (or ran out of iterations) stores its
-//     frame and loads the next one while the other three groups keep iterating.
+//   * lane groups are persistent: a group that converged (or ran out of iterations) stores its frame and sets
+//     the next one up while the other groups keep iterating.  The next frame's channel values are already in
+//     LDS by then: global_load_lds copied them there (no VGPR on the way, so nothing the register allocator
+//     could hand to a live value while a load is in flight) during the whole lifetime of the current frame.
 //
 // Numerics are those of minsum_reg.hip (same exclusive-minimum / sign identities, same argument for
 // zeros); configurations outside that argument use the generic kernel.
@@ -160,9 +163,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   char *cy_base = smem + wid * WAVE_BYTES;
   char *cn_lane = cy_base + CY_BYTES + ((fl >> 1) - fl) * RC * 8 + (fl & 1) * 4;  // + aCY[d] -> CN slot
   uint32_t *cbits = reinterpret_cast<uint32_t *>(smem + 4 * WAVE_BYTES);  // [256] per workgroup
-  // 256 bytes per wavefront that absorb the look-ahead loads (see the load block)
-  const uint32_t lds_sink = __builtin_amdgcn_readfirstlane(
-      static_cast<uint32_t>(reinterpret_cast<size_t>(smem + 4 * WAVE_BYTES + 1024 + wid * 256)));
+  // STG[c][lane]: channel values of the frame each group decodes NEXT, written by global_load_lds (no VGPR on the
+  // way) while the current frame iterates; CPL x 256 bytes per wavefront
+  char *stg = smem + 4 * WAVE_BYTES + 1024 + wid * (CPL * 256);
+  const uint32_t stg_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<size_t>(stg)));
   cbits[threadIdx.x] = colbits[threadIdx.x];
   __syncthreads();
 
@@ -196,45 +200,50 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
   float Q[NEEDQ ? K : 1][NEEDQ ? D : 1];
 
+  // asynchronous copy of frame f's channel values into STG (lanes of this group only; EXEC is the caller's)
+  auto stage = [&](unsigned long long f) {
+    if (f < B) {
+      const float *src = llr + f * n;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lam + LPF * c;
+        if (j < n) {
+          uint32_t m0_save;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(m0_save) : "v"(src + j), "s"(stg_lds + c * 256) : "memory");
+        }
+      }
+    }
+  };
+  // set a frame up from channel values yv: {cs = 0, y}, cs' = 0, all messages 0 (soft_decision.h:168-170)
+  auto setup = [&](unsigned long long f, float (&yv)[CPL]) {
+    if (er_off != nullptr) {  // cyclic.h:259-262
+      for (uint32_t e = er_off[f]; e < er_off[f + 1]; ++e) {
+        const int pos = er[e];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (pos == lam + LPF * c) yv[c] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, yv[c]);
+      *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
+    }
+    static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+    if constexpr (NEEDQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+  };
+
   while (__any(active)) {
-    if (need_load && active) {  // per 16-lane group
+    if (need_load && active) {  // first frame of a group: plain loads; every later frame arrives through STG
       float yv[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int j = lam + LPF * c;
         yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
       }
-      // Touch the frame this group decodes next: one load per 64-byte line brings it into L2 while the current
-      // frame iterates.  The data is never used, so it must not land in a VGPR the allocator may hand to a live
-      // value before the load returns: global_load_lds writes it to a scratch line of LDS instead (M0 = LDS
-      // address, saved and restored inside the block).
-      if (frame + ngroups < B) {
-        const float *nxt = llr + (frame + ngroups) * n;
-#pragma unroll
-        for (int c = 0; c < (LPF * CPL + 16 * LPF - 1) / (16 * LPF); ++c) {
-          const int j = 16 * (lam + LPF * c);  // one load per 64-byte line
-          if (j < n) {
-            uint32_t m0_save;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_save) : "v"(nxt + j), "s"(lds_sink) : "memory");
-          }
-        }
-      }
-      if (er_off != nullptr) {  // cyclic.h:259-262
-        for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
-          const int pos = er[e];
-#pragma unroll
-          for (int c = 0; c < CPL; ++c)
-            if (pos == lam + LPF * c) yv[c] = 0.0f;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, yv[c]);
-        *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
-      }
-      static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
-      if constexpr (NEEDQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+      stage(frame + ngroups);
+      setup(frame, yv);
       it = 0;
       need_load = false;
     }
@@ -341,23 +350,42 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       ok = group_or<LPF>(any) == 0;
     const bool finished = ok || (it + 1 >= p.iterations);
     if (finished && active) {
+      // results of the decided frame out of LDS first: its {cs, y} slots are about to be reused
+      const unsigned long long done = frame;
+      float Lc[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
+        Lc[c] = cy.x + cy.y;
+      }
+      const unsigned done_it = ok ? it : p.iterations;
+      frame += ngroups;
+      active = frame < B;
+      if (active) {
+        // the next frame was staged a whole frame ago; nothing else of this wave is in flight, so the wait is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float yv[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int j = lam + LPF * c;
+          yv[c] = (j < n) ? (*reinterpret_cast<const float *>(stg + c * 256 + lane * 4) + 0.0f) : 0.0f;
+        }
+        setup(frame, yv);
+        it = 0;
+      }
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int j = lam + LPF * c;
         if (j < n) {
-          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
-          const float Lc = cy.x + cy.y;
-          hard[frame * n + j] = (Lc < 0.0f) ? 1 : 0;
-          if (Lout) Lout[frame * n + j] = Lc;
+          hard[done * n + j] = (Lc[c] < 0.0f) ? 1 : 0;
+          if (Lout) Lout[done * n + j] = Lc[c];
         }
       }
       if (lam == 0) {
-        if (iters_out) iters_out[frame] = static_cast<uint16_t>(ok ? it : p.iterations);
-        if (status_out) status_out[frame] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
+        if (iters_out) iters_out[done] = static_cast<uint16_t>(done_it);
+        if (status_out) status_out[done] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
       }
-      frame += ngroups;
-      active = frame < B;
-      need_load = true;
+      if (active) stage(frame + ngroups);  // after the reads of STG above have been consumed
     } else {
       ++it;
     }
