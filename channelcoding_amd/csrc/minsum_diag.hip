@@ -1,6 +1,7 @@
 // minsum_diag.hip -- host side of the diagonal-parallel min-sum kernel (geometry table, dealing of the diagonals
-// to lanes, dispatch) and the instantiations for n = 255 and n = 127; the kernel itself is minsum_diag_impl.hpp,
-// the instantiations for n <= 63 are compiled in minsum_diag_small.hip (two translation units build in parallel).
+// to lanes, dispatch) and the instantiations for n = 255; the kernel itself is minsum_diag_impl.hpp, the
+// instantiations for n = 127 and n <= 63 are compiled in minsum_diag_127.hip / minsum_diag_small.hip (three
+// translation units build in parallel).
 #include "minsum_diag_impl.hpp"
 
 namespace ccamd {
@@ -146,6 +147,8 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
   if (!g) return CC_ERR_UNSUPPORTED;
   if (g->n <= 63)
     return launch_minsum_diag_small(code, *g, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
+  if (g->n == 127)
+    return launch_minsum_diag_127(code, *g, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 #define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
   if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
   return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
@@ -163,10 +166,6 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
   }
   CC_GEO_S(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD (one for SCMS1/2)
   CC_GEO_S(8, 8, 16, 16, 3);  // BCH(255,247), self-correcting variants included (128 message registers)
-  CC_GEO_S(7, 8, 8, 16, 3);   // BCH(127,120)
-  CC_GEO_S(14, 7, 8, 16, 2);  // BCH(127,113): 98 message registers
-  CC_GEO_S(21, 6, 8, 16, 2);  // BCH(127,106): 126 message registers
-  CC_GEO(28, 7, 8, 16, 1);    // BCH(127,99): 196 message registers
 #undef CC_GEO
 #undef CC_GEO_S
   return CC_ERR_UNSUPPORTED;
