@@ -42,6 +42,8 @@ struct WaveScratch {
   uint8_t S[64];    // syndromes
   uint8_t lam[72];  // lambda coefficients
   uint8_t om[72];   // omega coefficients
+  uint8_t rp[64];   // positions of the located errors, in ascending position order
+  uint8_t val[64];  // their values
 };
 
 __device__ __forceinline__ uint32_t bcast63(uint32_t v) { return __builtin_amdgcn_readlane(v, 63); }
@@ -216,7 +218,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
       if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
 
       // ---- root search: position p is in error iff lambda(alpha^-p) = 0 ----
-      uint32_t isroot[4] = {0, 0, 0, 0};
+      uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
       if (status == CC_FRAME_OK) {
         uint32_t acc[4];
         const uint32_t lead = W.lam[deg];
@@ -228,10 +230,13 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
           for (int c = 0; c < 4; ++c) acc[c] = gmul_pow(acc[c], xinv[c]) ^ lj;
         }
         int count = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           isroot[c] = (valid[c] && acc[c] == 0) ? 1u : 0u;
-          count += __builtin_popcountll(__ballot(isroot[c] != 0));
+          const unsigned long long mk = __ballot(isroot[c] != 0);
+          rank[c] = static_cast<uint32_t>(count + __builtin_popcountll(mk & below));
+          count += __builtin_popcountll(mk);
         }
         nerr = count;
         if (count != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
@@ -249,16 +254,25 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
           om ^= gmul(lm, s);
         }
         W.om[lane] = static_cast<uint8_t>(om);
+        // one lane per located error (ranks from the ballots of the root search) instead of a Horner chain over
+        // every position: numerator omega(X^-1), denominator lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          // numerator omega(X^-1), denominator lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+        for (int c = 0; c < 4; ++c)
+          if (isroot[c]) W.rp[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
+        uint32_t y = 0;
+        if (lane < deg) {
+          const uint32_t p = W.rp[lane];
+          const uint32_t xi = p ? static_cast<uint32_t>(nn) - p : 0u;
+          const uint32_t x2 = (2 * xi) % static_cast<uint32_t>(nn);
           uint32_t num = 0, den = 0;
-          for (int j = deg - 1; j >= 0; --j) num = gmul_pow(num, xinv[c]) ^ W.om[j];
-          const uint32_t x2 = (2 * xinv[c]) % static_cast<uint32_t>(nn);
+          for (int j = deg - 1; j >= 0; --j) num = gmul_pow(num, xi) ^ W.om[j];
           const int mtop = (deg & 1) ? deg : deg - 1;
           for (int m = mtop; m >= 1; m -= 2) den = gmul_pow(den, x2) ^ W.lam[m];
-          yv[c] = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
+          y = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
         }
+        W.val[lane] = static_cast<uint8_t>(y);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yv[c] = isroot[c] ? W.val[rank[c]] : 0u;
       }
 
       // ---- verify: syndromes of the error pattern must equal the received syndromes (cyclic.h:243-248) ----
