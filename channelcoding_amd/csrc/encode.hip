@@ -106,6 +106,47 @@ encode_bch_bits_kernel(const uint8_t *__restrict__ PT, const uint8_t *__restrict
   }
 }
 
+// Binary generator (BCH), any symbol values of GF(2^q): parity symbol i is the XOR of the message symbols m_j
+// with bit i of P[j] set (x^(k+j) mod g has 0/1 coefficients), i.e. the bit-parallel kernel above applied to each
+// of the q bit planes of the symbols: q masked XORs per message position instead of k multiply-accumulates.
+__global__ void __launch_bounds__(256)
+encode_bch_planes_kernel(const uint8_t *__restrict__ PT, const uint8_t *__restrict__ msg, uint8_t *__restrict__ cw, int n,
+                         int k, int l, int q, unsigned long long B) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t P[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = lane + 64 * c;
+    P[c] = 0;
+    if (j < l)
+      for (int i = 0; i < k; ++i) P[c] |= static_cast<uint32_t>(PT[i * l + j] & 1u) << i;
+  }
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+    uint32_t m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      m[c] = j < l ? (msg[f * l + j] & static_cast<uint32_t>(n)) : 0u;
+    }
+    uint32_t par = 0;  // parity symbol of position `lane` (lane < k), assembled plane by plane
+    for (int b = 0; b < q; ++b) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc ^= P[c] & (0u - ((m[c] >> b) & 1u));
+      acc = __builtin_amdgcn_readlane(wave_xor(acc), 63);
+      par |= ((acc >> lane) & 1u) << b;
+    }
+    if (lane < k) cw[f * n + lane] = static_cast<uint8_t>(par);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      if (j < l) cw[f * n + k + j] = static_cast<uint8_t>(m[c]);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 encode_multiplication_kernel(const AlgebraicTables *__restrict__ T, const uint8_t *__restrict__ msg,
                              uint8_t *__restrict__ cw, unsigned long long B) {
@@ -234,6 +275,10 @@ int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size
   const unsigned long long Bq = B;
   if (code->desc.coding == CC_CODING_MULTIPLICATION) {
     hipLaunchKernelGGL(encode_multiplication_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, d_msg, d_cw, Bq);
+  } else if (code->tab.family == CC_FAMILY_BCH && code->tab.k <= 32 && code->d_parity != nullptr) {
+    hipLaunchKernelGGL(encode_bch_planes_kernel, dim3(grid), dim3(256), 0, stream, code->d_parity, d_msg, d_cw,
+                       static_cast<int>(code->tab.n), static_cast<int>(code->tab.k), static_cast<int>(code->tab.l),
+                       static_cast<int>(code->tab.q), Bq);
   } else {
     const size_t lds = 768 + 1024 + static_cast<size_t>(code->tab.k) * code->tab.l;
     if (lds > 64 * 1024) {

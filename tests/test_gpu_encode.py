@@ -140,3 +140,21 @@ def test_decode_entry_points():
     assert np.array_equal(a["msg"], b["out"][:, soft.k:])
     hardf = cc.primitive_bch(6, cc.errors(3), cc.berlekamp_massey_tag()).decode_batch(y)
     assert np.array_equal(hardf["msg"], hardf["out"][:, soft.k:]) and (hardf["status"] == 0).any()
+
+
+@pytest.mark.parametrize("q,t", [(4, 2), (5, 3), (6, 3), (7, 2), (8, 3), (8, 4), (8, 5)])
+def test_bch_encode_accepts_any_field_element(q, t):
+    """The reference's BCH codes carry GF(2^q) elements as symbols (cyclic.h:300-301): a message symbol may be any
+    field element, and the parity symbols are then XORs of such elements.  The bit-plane encoder (k <= 32) and the
+    table encoder (k > 32) must both agree with the oracle."""
+    o = Oracle(BCH, q, t)
+    code = cc.primitive_bch(q, cc.errors(t), cc.berlekamp_massey_tag())
+    rng = np.random.default_rng(40 * q + t)
+    msg = rng.integers(0, o.n + 1, (777, o.l)).astype(np.uint8)
+    msg[0] = 0
+    msg[1] = o.n
+    cw = code.encode_batch(msg)
+    assert np.array_equal(cw, o.encode(msg))
+    assert np.array_equal(code.extract_batch(cw), msg)
+    bits = (msg & 1).astype(np.uint8)
+    assert np.array_equal(code.encode_batch(bits), o.encode(bits))
