@@ -134,7 +134,7 @@ std::string minsum_diag_name(const cc_code *code) {
 
 size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
   const bool partial = g.w != static_cast<unsigned>(g.LPF * g.D);
-  const size_t fpw = 64 / g.LPF, rc = static_cast<size_t>(g.LPF) * g.CPL + (partial ? 48 : 16);
+  const size_t fpw = 64 / g.LPF, rc = static_cast<size_t>(g.LPF) * g.CPL + (partial ? 48 : (g.LPF == 8 && g.CPL == 8 ? 8 : 16));
   return 4 * (fpw * rc * 8 + (fpw / 2) * rc * 8) + 256 * 4 +  // + column masks
          4 * static_cast<size_t>(g.CPL) * 256;                 // + staging area of the next frames
 }

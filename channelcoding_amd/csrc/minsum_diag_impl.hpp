@@ -151,7 +151,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   constexpr int FPW = 64 / LPF;          // frames per wavefront
   // columns of one frame's LDS region: + 16 pad (odd frames start 16 banks later); PARTIAL geometries (row weight
   // not a multiple of LPF) append 32 scratch columns that absorb the accesses of the lanes whose last slot is empty
-  constexpr int RC = LPF * CPL + (PARTIAL ? 48 : 16);
+  constexpr int RC = LPF * CPL + (PARTIAL ? 48 : (LPF == 8 && CPL == 8 ? 8 : 16));  // n = 63: 8 measured best (683 vs 646 M frames/s)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // CY: one float2 {cs, y} per column, frame f at f * RC.  CN: one float per column at an 8-byte
   // stride, the two frames of a 32-lane half interleaved on even / odd dwords (conflict-free, and the byte
