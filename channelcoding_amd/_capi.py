@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchannelcoding_amd.so")
+# CHANNELCODING_AMD_LIB: another build of the same library (kernel experiments under profiles/); never a fallback
+LIB_PATH = os.environ.get("CHANNELCODING_AMD_LIB") or os.path.join(_HERE, "libchannelcoding_amd.so")
 
 # enums of channelcoding_amd.h
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_LENGTH, ERR_NOT_IN_FIELD = range(8)
