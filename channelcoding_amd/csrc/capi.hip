@@ -230,7 +230,11 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colmask), cm.size() * sizeof(uint32_t)));
     CC_HIP_TRY(hipMemcpy(code->d_colmask, cm.data(), cm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (const DiagGeometry *dgeo = code->custom_H.empty() ? diag_geometry(t) : nullptr) {
-      const std::vector<uint16_t> dg = build_diag_table(t, dgeo->D, dgeo->LPF);
+      const std::vector<uint16_t> dg = build_diag_table(t, dgeo->D, dgeo->LPF, dgeo->np, dgeo->gap);
+      if (dg.empty()) {
+        set_last_error("no paired deal of the row-0 support for this geometry's gaps");
+        return CC_ERR_UNSUPPORTED;
+      }
       std::vector<uint32_t> cb(256, 0u);
       for (unsigned j = 0; j < t.n; ++j)
         for (unsigned i = 0; i < t.k && i <= j; ++i)

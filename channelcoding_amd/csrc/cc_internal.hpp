@@ -99,9 +99,11 @@ struct DiagGeometry {
   unsigned n, k, w;  // code length, rows of H, row weight
   int D, LPF, CPL;   // diagonals per lane, lanes per frame, columns per lane
   bool scms;         // 2 K D registers fit: the self-correcting variants are instantiated too
+  int np = 0;        // paired slots: slots 2p and 2p+1 of every lane hold diagonals s and s + gap[p] (one
+  int gap[4] = {0, 0, 0, 0};  // two-address LDS instruction serves both); the remaining D - 2 np slots are singles
 };
 const DiagGeometry *diag_geometry(const CodeTables &t);  // nullptr: no diagonal kernel for this code
-std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W);
+std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np = 0, const int *gap = nullptr);
 size_t minsum_diag_lds_bytes(const DiagGeometry &g);
 bool minsum_diag_supported(const cc_code *code);
 int launch_minsum_diag_127(const cc_code *code, const DiagGeometry &g, const MinSumParams &p, const float *d_llr,

@@ -4,13 +4,15 @@
 // translation units build in parallel).
 #include "minsum_diag_impl.hpp"
 
+#include <algorithm>
+
 namespace ccamd {
 
 // Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
 // in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
 static const DiagGeometry kDiagGeometries[] = {
     // n,   k,  w,  D, LPF, CPL, SCMS1/2     (w < LPF * D: the last slot of some lanes is empty, "partial")
-    {255, 24, 112, 7, 16, 16, true},   // BCH(255,231)
+    {255, 24, 112, 7, 16, 16, true},   // BCH(255,231) (paired slots {3, 4, 6} measured slower: profiles/r02_experiments.md E3)
     {255, 16, 120, 8, 16, 16, true},  // BCH(255,239), partial
     {255, 32, 124, 8, 16, 16, false}, // BCH(255,223), partial; one wave per SIMD
     {255, 8, 128, 8, 16, 16, true},    // BCH(255,247)
@@ -36,10 +38,95 @@ const DiagGeometry *diag_geometry(const CodeTables &t) {
   return nullptr;
 }
 
-// Deal the row-0 support (w = W * D diagonals) to W lanes x D slots so that, within a slot, the W values are as
-// distinct as possible modulo 16: the frames of a 32-lane half sit in regions that start 16 banks apart, so
-// residues mod 16 decide bank conflicts.
-std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W) {
+// Paired deal: np slot pairs (2p, 2p+1) whose diagonals differ by gap[p] in EVERY lane, so that the two columns a
+// lane touches in such a pair sit a compile-time constant apart and one two-address LDS instruction
+// (ds_read2_b64 / ds_read2_b32 / ds_write2_b32) serves both edges.  Needs W disjoint pairs (s, s + gap[p]) of the
+// support per p, all np W pairs disjoint; the rest of the support fills the single slots.  Randomised greedy
+// with a fixed seed (deterministic), keeping the deal with the fewest LDS passes (lanes of a frame whose
+// diagonals agree modulo 16 share a bank).  Empty result: no such deal exists for these gaps.
+static std::vector<uint16_t> build_paired_table(const CodeTables &t, int D, int W, int np, const int *gap) {
+  const std::vector<unsigned> &sup = t.row0_support;
+  std::vector<char> in_sup(t.n + 512, 0);
+  for (unsigned s : sup) in_sup[s] = 1;
+  const int singles_per_lane = D - 2 * np;
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto next = [&]() {
+    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+    return static_cast<uint32_t>(rng >> 33);
+  };
+  auto passes = [&](const std::vector<unsigned> &v) {
+    int cnt[16] = {0}, mx = 0;
+    for (unsigned s : v) mx = std::max(mx, ++cnt[s % 16]);
+    return mx;
+  };
+  int best_cost = 1 << 30;
+  std::vector<std::vector<unsigned>> best_low;
+  std::vector<unsigned> best_single;
+  for (int attempt = 0; attempt < 4000 && best_cost > np + singles_per_lane; ++attempt) {
+    std::vector<char> used(t.n + 512, 0);
+    std::vector<std::vector<unsigned>> low(np);
+    bool ok = true;
+    for (int p = 0; p < np && ok; ++p) {
+      std::vector<unsigned> c;
+      for (unsigned s : sup)
+        if (in_sup[s + gap[p]]) c.push_back(s);
+      for (size_t i = c.size(); i > 1; --i) std::swap(c[i - 1], c[next() % i]);
+      bool res[16] = {false};
+      for (int pass = 0; pass < 2 && low[p].size() < static_cast<size_t>(W); ++pass)  // distinct residues first
+        for (unsigned s : c) {
+          if (used[s] || used[s + gap[p]] || (pass == 0 && res[s % 16])) continue;
+          used[s] = used[s + gap[p]] = 1;
+          res[s % 16] = true;
+          low[p].push_back(s);
+          if (low[p].size() == static_cast<size_t>(W)) break;
+        }
+      ok = low[p].size() == static_cast<size_t>(W);
+    }
+    if (!ok) continue;
+    std::vector<unsigned> single;
+    for (unsigned s : sup)
+      if (!used[s]) single.push_back(s);
+    int cost = 0;
+    for (int p = 0; p < np; ++p) cost += passes(low[p]);
+    // singles: dealt to their slots below by residue class, cost = ceil(max class size / slots) per slot at best
+    {
+      int cnt[16] = {0}, mx = 0;
+      for (unsigned s : single) mx = std::max(mx, ++cnt[s % 16]);
+      cost += std::max(singles_per_lane, mx);
+    }
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_low = low;
+      best_single = single;
+    }
+  }
+  if (best_cost == 1 << 30) return {};
+  std::vector<uint16_t> out(static_cast<size_t>(D) * W, 0xFFFFu);
+  for (int p = 0; p < np; ++p) {
+    std::sort(best_low[p].begin(), best_low[p].end());
+    for (int l = 0; l < W; ++l) {
+      out[(2 * p) * W + l] = static_cast<uint16_t>(best_low[p][l]);
+      out[(2 * p + 1) * W + l] = static_cast<uint16_t>(best_low[p][l] + gap[p]);
+    }
+  }
+  // single slots: round-robin over the residue classes so that equal residues land in different slots
+  std::vector<std::vector<unsigned>> cls(16);
+  for (unsigned s : best_single) cls[s % 16].push_back(s);
+  std::vector<std::vector<unsigned>> slot(singles_per_lane);
+  int turn = 0;
+  for (int r = 0; r < 16; ++r)
+    for (unsigned s : cls[r]) {
+      int tries = 0;
+      while (slot[turn % singles_per_lane].size() >= static_cast<size_t>(W) && tries++ < singles_per_lane) ++turn;
+      slot[turn++ % singles_per_lane].push_back(s);
+    }
+  for (int g = 0; g < singles_per_lane; ++g)
+    for (size_t l = 0; l < slot[g].size(); ++l) out[(2 * np + g) * W + l] = static_cast<uint16_t>(slot[g][l]);
+  return out;
+}
+
+std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np, const int *gap) {
+  if (np > 0) return build_paired_table(t, D, W, np, gap);
   std::vector<std::vector<unsigned>> cls(W);
   for (unsigned s : t.row0_support) cls[s % W].push_back(s);
   std::vector<std::vector<unsigned>> grp(D);

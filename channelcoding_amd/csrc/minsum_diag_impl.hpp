@@ -51,6 +51,22 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
 }
+// Paired slots (see build_paired_table in minsum_diag.hip): slots 2p and 2p+1 hold diagonals s and s + G_p in every
+// lane, so both edges are addressed from ONE base register with compile-time offsets and the compiler merges the
+// two LDS accesses into ds_read2_b64 / ds_read2_b32 / ds_write2_b32.
+template <int... Gs>
+struct PairGaps {
+  static constexpr int NP = sizeof...(Gs);
+  static constexpr int gap(int p) {
+    constexpr int a[sizeof...(Gs) + 1] = {Gs..., 0};
+    return a[p];
+  }
+};
+template <typename PG>
+constexpr int slot_base(int d) { return d < 2 * PG::NP ? (d & ~1) : d; }
+template <typename PG>
+constexpr int slot_gap(int d) { return (d < 2 * PG::NP && (d & 1)) ? PG::gap(d >> 1) : 0; }
+
 // (a ^ b) + c in one VALU op
 __device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
@@ -64,39 +80,43 @@ __device__ __forceinline__ uint32_t dpp16(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-// one butterfly stage of the (min1, min2-with-multiplicity) all-reduce inside a 16-lane row
+// one butterfly stage of the (min1, min2-with-multiplicity, sign parity) all-reduce inside a 16-lane row.
+// Instruction order pinned: max_dpp(m1), min_dpp(m1), xor_dpp(sg), mov_dpp(m2), min3.  A DPP operand needs two
+// wait states after the VALU write of its register; in this order every register is written at least three
+// instructions before the next stage reads it through DPP, so no s_nop is issued (one per stage before).
 template <int CTRL>
-__device__ __forceinline__ void pair_stage(uint32_t &m1, uint32_t &m2) {
+__device__ __forceinline__ void reduce_stage(uint32_t &m1, uint32_t &m2, uint32_t &sg) {
   // all four patterns used here (quad_perm, row_half_mirror, row_mirror) read a valid lane everywhere, so the
   // `old` operand is never selected: mov_dpp leaves it undefined, update_dpp(m2, m2) would cost a v_mov to tie it
-  const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m2), CTRL, 0xF, 0xF, true));
-  const uint32_t lo = umin32(m1, dpp16<CTRL, 0xFFFFFFFFu>(m1));
   const uint32_t hi = umax32(m1, dpp16<CTRL, 0u>(m1));
-  m1 = lo;
+  __builtin_amdgcn_sched_barrier(0);
+  m1 = umin32(m1, dpp16<CTRL, 0xFFFFFFFFu>(m1));
+  __builtin_amdgcn_sched_barrier(0);
+  sg = sg ^ dpp16<CTRL, 0u>(sg);
+  __builtin_amdgcn_sched_barrier(0);
+  const uint32_t o2 = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(m2), CTRL, 0xF, 0xF, true));
+  __builtin_amdgcn_sched_barrier(0);
   m2 = umin32(hi, umin32(m2, o2));
+  __builtin_amdgcn_sched_barrier(0);
 }
 template <int CTRL>
 __device__ __forceinline__ uint32_t xor_stage(uint32_t v) { return v ^ dpp16<CTRL, 0u>(v); }
 template <int CTRL>
 __device__ __forceinline__ uint32_t or_stage(uint32_t v) { return v | dpp16<CTRL, 0u>(v); }
 
-// RB rows reduced together, stage-major (independent DPP ops back to back); LPF = lanes per frame (8 or 16)
+// RB rows reduced together, stage-major; LPF = lanes per frame (8 or 16)
 template <int RB, int LPF>
 __device__ __forceinline__ void row_allreduce(uint32_t (&m1)[RB], uint32_t (&m2)[RB], uint32_t (&sg)[RB]) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0xB1>(m1[r], m2[r]); sg[r] = xor_stage<0xB1>(sg[r]); }   // quad_perm [1,0,3,2]
-  __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < RB; ++r) reduce_stage<0xB1>(m1[r], m2[r], sg[r]);   // quad_perm [1,0,3,2]
 #pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0x4E>(m1[r], m2[r]); sg[r] = xor_stage<0x4E>(sg[r]); }   // quad_perm [2,3,0,1]
-  __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < RB; ++r) reduce_stage<0x4E>(m1[r], m2[r], sg[r]);   // quad_perm [2,3,0,1]
 #pragma unroll
-  for (int r = 0; r < RB; ++r) { pair_stage<0x141>(m1[r], m2[r]); sg[r] = xor_stage<0x141>(sg[r]); }  // row_half_mirror
-  __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < RB; ++r) reduce_stage<0x141>(m1[r], m2[r], sg[r]);  // row_half_mirror
   if constexpr (LPF == 16) {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) { pair_stage<0x140>(m1[r], m2[r]); sg[r] = xor_stage<0x140>(sg[r]); }  // row_mirror
-    __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < RB; ++r) reduce_stage<0x140>(m1[r], m2[r], sg[r]);  // row_mirror
   }
 }
 template <int LPF>
@@ -140,7 +160,7 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
 
 // K rows, D diagonals per lane (LPF * D = row weight), RB rows per reduction batch, LPF lanes per frame (64 / LPF
 // frames per wavefront), CPL columns per lane (LPF * CPL >= n), OCC = waves per SIMD the register budget targets
-template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL>
+template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL, typename PG = PairGaps<>>
 __global__ void __launch_bounds__(256, OCC)
 minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
                    const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
@@ -148,6 +168,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
                    int32_t *__restrict__ status_out, unsigned long long B) {
   static_assert(K % RB == 0 && K <= 32, "row batching");
   static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
+  static_assert(2 * PG::NP <= D && !(PARTIAL && PG::NP > 0), "paired slots");
   constexpr int FPW = 64 / LPF;          // frames per wavefront
   // columns of one frame's LDS region: + 16 pad (odd frames start 16 banks later); PARTIAL geometries (row weight
   // not a multiple of LPF) append 32 scratch columns that absorb the accesses of the lanes whose last slot is empty
@@ -252,7 +273,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
     // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
     float2 cyq[D];
-    static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD]); });
+    static_for<D>([&](auto DD) {
+      constexpr int d = DD;
+      cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * slot_gap<PG>(d));
+    });
     static_for<K>([&](auto IR) {
       constexpr int i = IR;
       uint32_t m1[1], m2[1], sg[1];
@@ -261,6 +285,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         // starting value of the reference's own search (soft_decision.h:110); with D >= 2 both are overwritten
         float a1 = 0.0f, a2 = (D == 1) ? 3.402823466e+38f : 0.0f;
         uint32_t s = 0;
+        uint32_t qs[D];
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
           float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
@@ -277,35 +302,54 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             a = __builtin_fmaxf(a, pen);
             qb &= sgn_keep;
           }
+          qs[d] = qb;
           if constexpr (d == 0) {
             a1 = a;
-            s = qb;
           } else if constexpr (d == 1) {
             a2 = __builtin_fmaxf(a1, a);
             a1 = __builtin_fminf(a1, a);
-            s ^= qb;
           } else {
             a2 = __builtin_amdgcn_fmed3f(a1, a, a2);
             a1 = __builtin_fminf(a1, a);
-            s ^= f2u(q);
           }
         });
+        // sign parity: three-input XORs (v_bitop3_b32), half the instructions of a chain of v_xor_b32
+        s = qs[0];
+        static_for<(D - 1) / 2>([&](auto T) {
+          s = static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int>(s), static_cast<int>(qs[1 + 2 * T]),
+                                                                static_cast<int>(qs[2 + 2 * T]), 0x96));  // a ^ b ^ c
+        });
+        if constexpr ((D - 1) % 2) s ^= qs[D - 1];
         m1[0] = f2u(a1);
         m2[0] = f2u(a2);
         sg[0] = s;
       }
       if constexpr (i + 1 < K)  // prefetch the next row's operands
-        static_for<D>([&](auto DD) { cyq[DD] = *reinterpret_cast<const float2 *>(cy_base + aCY[DD] + 8 * (i + 1)); });
-      float cn[D];
-      static_for<D>([&](auto DD) { cn[DD] = *reinterpret_cast<const float *>(cn_lane + aCY[DD] + 8 * i); });
-      row_allreduce<1, LPF>(m1, m2, sg);
-      const uint32_t sign31 = sg[0] & 0x80000000u;
-      if constexpr (VARIANT == CC_ALG_MS) {
-        const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          const uint32_t t = f2u(__builtin_amdgcn_fmed3f(__builtin_fabsf(R[i][d]), u2f(m1[0]), u2f(m2[0])));
-          R[i][d] = u2f(xad(t, Y, f2u(R[i][d]) & 0x80000000u));
+          cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (i + 1 + slot_gap<PG>(d)));
+        });
+      float cn[D];
+      static_for<D>([&](auto DD) {
+        constexpr int d = DD;
+        cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
+      });
+      row_allreduce<1, LPF>(m1, m2, sg);
+      // the parity leaves the last DPP stage in a register of its own: folded into the mask below, the compiler
+      // undoes the DPP form of that stage (a bit operation with three inputs takes no DPP operand)
+      asm volatile("" : "+v"(sg[0]));
+      const uint32_t sign31 = sg[0] & 0x80000000u;
+      if constexpr (VARIANT == CC_ALG_MS) {
+        // exclusive minimum with the exclusive sign in TWO instructions per edge: u = med3(q, -m2, m2) is
+        // sign(q) min(|q|, m2), i.e. +-m1 for the holder of the minimum and +-m2 for everybody else (|q| >= m2);
+        // XOR with m1 ^ m2 swaps the two magnitudes, XOR with the row parity (bit 31) turns sign(q) into the
+        // product of the OTHER signs.  A zero keeps its sign bit through med3, as it did through the old
+        // (t ^ Y) + signbit(q) form; with m1 = m2 = 0 the result is +-0 either way.
+        const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
+        const float hi = u2f(m2[0]);
+        static_for<D>([&](auto DD) {
+          constexpr int d = DD;
+          R[i][d] = u2f(f2u(__builtin_amdgcn_fmed3f(R[i][d], -hi, hi)) ^ Y);
         });
       } else {
         const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[0]), p.alpha_f, p.beta_d));
@@ -316,8 +360,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
         });
       }
+      // column sums: all D additions behind ONE wait (the last-issued read first: once it has arrived the others
+      // have too, LDS returns in order), then the D stores -- instead of a wait in front of every addition
+      float sum[D];
       static_for<D>([&](auto DD) {
-        *reinterpret_cast<float *>(cn_lane + aCY[DD] + 8 * i) = cn[DD] + R[i][DD];  // ascending rows
+        constexpr int d = D - 1 - DD;
+        sum[d] = cn[d] + R[i][d];  // ascending rows
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<D>([&](auto DD) {
+        constexpr int d = DD;
+        *reinterpret_cast<float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
       });
       // The next row reads column sums that OTHER lanes have just written (column s + i is diagonal s - 1 of
       // row i + 1).  The hardware keeps LDS operations of a wavefront in order; the compiler must too: per
@@ -397,7 +450,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 namespace {
 
-template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false>
+template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false, typename PG = PairGaps<>>
 int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
@@ -419,10 +472,10 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   hipError_t e = hipSuccess;
 #define CC_LAUNCH(V, O)                                                                                            \
   {                                                                                                                \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL>),         \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG>),     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                    \
     if (e == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL>), dim3(grid), dim3(256), lds, stream, p,    \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG>), dim3(grid), dim3(256), lds, stream, p, \
                          code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);\
   }
   switch (p.variant) {
