@@ -29,6 +29,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #include "cc_internal.hpp"
@@ -134,6 +135,29 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return LPF == 16 ? or_stage<0x140>(v) : v;
 }
 
+// |.|-modified minimum / maximum / median without the canonicalisation the compiler puts in front of fminf on a
+// value that comes straight from memory (the hardware instructions quiet a signalling NaN themselves)
+__device__ __forceinline__ float min_abs2(float a, float b) {
+  float r;
+  asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_abs2(float a, float b) {
+  float r;
+  asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float min_abs1(float a, float q) {
+  float r;
+  asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(q));
+  return r;
+}
+__device__ __forceinline__ float med3_abs1(float a1, float q, float a2) {
+  float r;
+  asm("v_med3_f32 %0, %1, |%2|, %3" : "=v"(r) : "v"(a1), "v"(q), "v"(a2));
+  return r;
+}
+
 __device__ __forceinline__ int signum(float v) { return (0.0f < v) - (v < 0.0f); }
 // variable-node functor of the self-correcting variants: q = fn(e + y, q_old)
 template <int VARIANT>
@@ -160,7 +184,11 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
 
 // K rows, D diagonals per lane (LPF * D = row weight), RB rows per reduction batch, LPF lanes per frame (64 / LPF
 // frames per wavefront), CPL columns per lane (LPF * CPL >= n), OCC = waves per SIMD the register budget targets
-template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL, typename PG = PairGaps<>>
+// SINGLE: every frame runs exactly one iteration (stop rule O0 "as shipped", or Iterations == 1): all messages
+// and column sums are zero when that iteration starts, so q = (0 - 0) + y = y (y is never -0.0f) -- no {cs, r}
+// operands, no subtraction / addition, and no message registers at all.
+template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL, typename PG = PairGaps<>,
+          bool SINGLE = false>
 __global__ void __launch_bounds__(256, OCC)
 minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
                    const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
@@ -213,72 +241,133 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
   unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * FPW + fl;
   bool active = frame < B;
-  bool need_load = true;
   unsigned it = 0;
-  float R[K][D];
+  float R[SINGLE ? 1 : K][SINGLE ? 1 : D];
   // self-correcting variants keep the previous variable->check message of every edge as well (instantiated
   // only where 2 K D registers fit, see kDiagGeometries)
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
-  float Q[NEEDQ ? K : 1][NEEDQ ? D : 1];
+  constexpr bool KEEPQ = NEEDQ && !SINGLE;
+  float Q[KEEPQ ? K : 1][KEEPQ ? D : 1];
 
-  // asynchronous copy of frame f's channel values into STG (lanes of this group only; EXEC is the caller's)
+  // Asynchronous copy of frame f's channel values into STG, no VGPR on the way.  EXEC is the caller's: the lanes of
+  // one group, or of several groups that finish in the same iteration -- so nothing here may depend on the group.
+  // X4: global_load_lds_dwordx4; lane t's 16 bytes land at M0 + instruction offset + 16 t and the instruction
+  // offset moves the global address too (profiles/ubench/ldsdma_probe2.hip).  Instruction c copies floats
+  // [4 LPF c, 4 LPF (c + 1)) of every active group's frame into block c of STG (1 KiB, lane-linear), M0 being set
+  // so that the shared offset lands there; the last instruction is shifted back to end on float n - 1 (it copies a
+  // few floats twice, it never reads past the frame).  NF + 1 instructions per frame instead of CPL.  Frames
+  // shorter than 4 LPF floats (n = 15, 31) keep the dword form, STG[c][lane].
+  constexpr bool X4 = (LPF * CPL - 1) >= 4 * LPF;
+  constexpr int NF = (LPF * CPL - 1) / (4 * LPF);  // instructions that start on a multiple of 4 LPF floats
   auto stage = [&](unsigned long long f) {
     if (f < B) {
       const float *src = llr + f * n;
+      if constexpr (X4) {
+        const float *v = src + 4 * lam;
+        const float *vt = v + (n - 4 * LPF);  // the shifted last copy
+        // one asm statement: M0 is changed behind the compiler's back and must be back before it looks again.
+        // Global bytes advance by 16 LPF per instruction (the offset field), the LDS side must advance by 1024.
+        uint32_t m0_save;
+        const uint32_t sb = __builtin_amdgcn_readfirstlane(stg_lds);  // (uniform already; pins it to an SGPR)
+        static_assert(NF == 1 || NF == 3, "x4 staging is written out for one or three aligned copies");
+        if constexpr (NF == 3) {
+          asm volatile(
+              "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+              "s_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%7\n\t"
+              "s_add_u32 m0, %3, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%8\n\t"
+              "s_add_u32 m0, %3, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+              : "=&s"(m0_save)
+              : "v"(v), "v"(vt), "s"(sb), "n"(1024 - LPF * 16), "n"(2048 - 2 * LPF * 16), "n"(3072), "n"(LPF * 16),
+                "n"(2 * LPF * 16)
+              : "memory", "scc");
+        } else {
+          asm volatile(
+              "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+              "s_add_u32 m0, %3, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+              : "=&s"(m0_save)
+              : "v"(v), "v"(vt), "s"(sb)
+              : "memory", "scc");
+        }
+      } else {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int j = lam + LPF * c;
-        if (j < n) {
-          uint32_t m0_save;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(m0_save) : "v"(src + j), "s"(stg_lds + c * 256) : "memory");
+        for (int c = 0; c < CPL; ++c) {
+          const int j = lam + LPF * c;
+          if (j < n) {
+            uint32_t m0_save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_save) : "v"(src + j), "s"(stg_lds + c * 256) : "memory");
+          }
         }
       }
     }
   };
-  // set a frame up from channel values yv: {cs = 0, y}, cs' = 0, all messages 0 (soft_decision.h:168-170)
-  auto setup = [&](unsigned long long f, float (&yv)[CPL]) {
+  // channel value of column lam + LPF c of the frame staged for this group.  X4 layout: float e of the frame sits
+  // 4 (e mod 4 LPF) bytes into its group's 16 LPF-byte slice of block e / (4 LPF); the floats of the shifted last
+  // block are counted from n - 4 LPF.
+  const char *stg_full = stg + fl * LPF * 16 + lam * 4;
+  const char *stg_tail = stg + NF * 1024 + fl * LPF * 16 + (lam - n + 4 * LPF) * 4;
+  auto staged = [&](int c) -> float {
+    if constexpr (X4) {
+      if (c < 4 * NF) return *reinterpret_cast<const float *>(stg_full + (c / 4) * 1024 + (c % 4) * 4 * LPF);
+      return *reinterpret_cast<const float *>(stg_tail + 4 * LPF * c);
+    } else {
+      return *reinterpret_cast<const float *>(stg + c * 256 + lane * 4);
+    }
+  };
+  // set a frame up from the staged channel values: {cs = 0, y}, all messages 0 (soft_decision.h:168-170); cs' is
+  // zero already (cleared once below, and by the stop test of every iteration since).  Only the last owned column
+  // can lie beyond the frame (LPF (CPL - 1) < n <= LPF CPL for every geometry, checked by the launcher).
+  auto setup = [&](unsigned long long f) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      float y = staged(c) + 0.0f;  // -0.0f -> +0.0f
+      if (c == CPL - 1 && lam + LPF * c >= n) y = 0.0f;
+      *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, y);
+    }
     if (er_off != nullptr) {  // cyclic.h:259-262
       for (uint32_t e = er_off[f]; e < er_off[f + 1]; ++e) {
         const int pos = er[e];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c)
-          if (pos == lam + LPF * c) yv[c] = 0.0f;
+        if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + 4) = 0.0f;
       }
     }
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, yv[c]);
-      *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
-    }
-    static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
-    if constexpr (NEEDQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+    if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+    if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
   };
 
-  while (__any(active)) {
-    if (need_load && active) {  // first frame of a group: plain loads; every later frame arrives through STG
-      float yv[CPL];
+  // first frame of every group: staged like all the others, then the one after it
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int j = lam + LPF * c;
-        yv[c] = (j < n) ? (llr[frame * n + j] + 0.0f) : 0.0f;  // -0.0f -> +0.0f
-      }
-      stage(frame + ngroups);
-      setup(frame, yv);
-      it = 0;
-      need_load = false;
-    }
+  for (int c = 0; c < CPL; ++c) *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
+  if (active) {
+    stage(frame);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    setup(frame);
+    stage(frame + ngroups);
+  }
 
+  while (__any(active)) {
     // ---------------- one min-sum iteration for the four resident frames ----------------
     // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
     // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
     float2 cyq[D];
     static_for<D>([&](auto DD) {
       constexpr int d = DD;
-      cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * slot_gap<PG>(d));
+      const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * slot_gap<PG>(d);
+      if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
+      else cyq[d] = *reinterpret_cast<const float2 *>(a);
     });
     static_for<K>([&](auto IR) {
       constexpr int i = IR;
+      // q, then r, of this row's edges: the message registers, or temporaries when nothing is kept
+      // (accessors with literal indices: a reference to R[i] would keep the whole array out of registers)
+      float Tloc[D];
+      auto wget = [&](auto DD) -> float {
+        if constexpr (SINGLE) return Tloc[DD];
+        else return R[i][DD];
+      };
+      auto wset = [&](auto DD, float v) {
+        if constexpr (SINGLE) Tloc[DD] = v;
+        else R[i][DD] = v;
+      };
       uint32_t m1[1], m2[1], sg[1];
       {
         // with one diagonal per lane the lane's second minimum is "none": numeric_limits<float>::max(), the
@@ -288,14 +377,20 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         uint32_t qs[D];
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
-          if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
-          float q = e + cyq[d].y;                                             // :136,:207-209
-          if constexpr (NEEDQ) {
-            q = self_correct<VARIANT>(q, Q[i][d]);
-            Q[i][d] = q;
+          float q;
+          if constexpr (SINGLE) {
+            q = cyq[d].y;
+            if constexpr (NEEDQ) q = self_correct<VARIANT>(q, 0.0f);
+          } else {
+            float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
+            if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
+            q = e + cyq[d].y;                                                   // :136,:207-209
+            if constexpr (NEEDQ) {
+              q = self_correct<VARIANT>(q, Q[i][d]);
+              Q[i][d] = q;
+            }
           }
-          R[i][d] = q;
+          wset(DD, q);
           float a = __builtin_fabsf(q);
           uint32_t qb = f2u(q);
           if constexpr (PARTIAL && d == D - 1) {
@@ -303,7 +398,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             qb &= sgn_keep;
           }
           qs[d] = qb;
-          if constexpr (d == 0) {
+          if constexpr (SINGLE && !PARTIAL && D >= 2) {  // q is a loaded value here: see min_abs2
+            if constexpr (d == 0) {
+              a1 = q;  // |.| taken by the first use
+            } else if constexpr (d == 1) {
+              a2 = max_abs2(a1, q);
+              a1 = min_abs2(a1, q);
+            } else {
+              a2 = med3_abs1(a1, q, a2);
+              a1 = min_abs1(a1, q);
+            }
+          } else if constexpr (d == 0) {
             a1 = a;
           } else if constexpr (d == 1) {
             a2 = __builtin_fmaxf(a1, a);
@@ -327,7 +432,9 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       if constexpr (i + 1 < K)  // prefetch the next row's operands
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (i + 1 + slot_gap<PG>(d)));
+          const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * (i + 1 + slot_gap<PG>(d));
+          if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
+          else cyq[d] = *reinterpret_cast<const float2 *>(a);
         });
       float cn[D];
       static_for<D>([&](auto DD) {
@@ -349,15 +456,15 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         const float hi = u2f(m2[0]);
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          R[i][d] = u2f(f2u(__builtin_amdgcn_fmed3f(R[i][d], -hi, hi)) ^ Y);
+          wset(DD, u2f(f2u(__builtin_amdgcn_fmed3f(wget(DD), -hi, hi)) ^ Y));
         });
       } else {
         const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[0]), p.alpha_f, p.beta_d));
         const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[0]), p.alpha_f, p.beta_d));
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          const uint32_t mag = (__builtin_fabsf(R[i][d]) == u2f(m1[0])) ? H2 : H1;
-          R[i][d] = u2f(xad(mag, sign31, f2u(R[i][d]) & 0x80000000u));
+          const uint32_t mag = (__builtin_fabsf(wget(DD)) == u2f(m1[0])) ? H2 : H1;
+          wset(DD, u2f(xad(mag, sign31, f2u(wget(DD)) & 0x80000000u)));
         });
       }
       // column sums: all D additions behind ONE wait (the last-issued read first: once it has arrived the others
@@ -365,7 +472,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       float sum[D];
       static_for<D>([&](auto DD) {
         constexpr int d = D - 1 - DD;
-        sum[d] = cn[d] + R[i][d];  // ascending rows
+        sum[d] = cn[d] + wget(std::integral_constant<int, d>{});  // ascending rows
       });
       __builtin_amdgcn_sched_barrier(0);
       static_for<D>([&](auto DD) {
@@ -380,58 +487,73 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     });
 
     // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
-    uint32_t pv = 0, any = 0;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const int j = lam + LPF * c;
-      const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
-      const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
-      const bool bit = (j < n) && (cnv + yc < 0.0f);  // L = cs + y :180-182, b = L < 0 codes.h:51
-      const uint32_t cb = cbits[j];
-      pv ^= bit ? cb : 0u;
-      any |= bit ? cb : 0u;
-      // next iteration: cs := cs', cs' := 0
-      *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
-      *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
-    }
-    bool ok;
-    if (p.stop_rule == CC_STOP_AS_SHIPPED)
-      ok = true;
-    else if (p.stop_rule == CC_STOP_PARITY)
-      ok = group_xor<LPF>(pv) == 0;
-    else
-      ok = group_or<LPF>(any) == 0;
-    const bool finished = ok || (it + 1 >= p.iterations);
-    if (finished && active) {
-      // results of the decided frame out of LDS first: its {cs, y} slots are about to be reused
-      const unsigned long long done = frame;
-      float Lc[CPL];
+    // acc: XOR of the check masks of the columns whose hard decision is 1 (the frame's syndrome, GF(2) rule O2) or
+    // their OR (rule O1: only the all-zero word passes).  Only the last owned column can lie beyond the frame.
+    uint32_t acc = 0;
+    auto stop_scan = [&](auto ORC) {
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
-        Lc[c] = cy.x + cy.y;
+        const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
+        const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
+        bool bit = cnv + yc < 0.0f;  // L = cs + y :180-182, b = L < 0 codes.h:51
+        if (c == CPL - 1) bit = bit && (lam + LPF * c < n);
+        const uint32_t cb = bit ? cbits[lam + LPF * c] : 0u;
+        if constexpr (decltype(ORC)::value) acc |= cb;
+        else acc ^= cb;
+        // next iteration: cs := cs', cs' := 0
+        *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
+        *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
       }
-      const unsigned done_it = ok ? it : p.iterations;
+    };
+    bool ok;
+    if (p.stop_rule == CC_STOP_PUBLISHED) {
+      stop_scan(std::true_type{});
+      ok = group_or<LPF>(acc) == 0;
+    } else {
+      stop_scan(std::false_type{});
+      ok = (p.stop_rule == CC_STOP_AS_SHIPPED) || group_xor<LPF>(acc) == 0;
+    }
+    const bool finished = SINGLE || ok || (it + 1 >= p.iterations);
+    if (finished && active) {
+      const unsigned long long done = frame;
+      const unsigned done_it = ok ? it : p.iterations;  // (SINGLE without convergence: Iterations == 1)
       frame += ngroups;
       active = frame < B;
+      uint8_t *hp = hard + done * n + lam;
+      float *Lp = Lout ? Lout + done * n + lam : nullptr;
+      // column by column: result of the decided frame out of LDS, the next frame's channel value in, result to
+      // HBM -- nothing is held in registers across columns.  The wait comes before the first store: the next frame
+      // was staged a whole frame ago and nothing else of this wave is in flight, so it is free.
+      auto emit = [&](int c, float L) {
+        if (c < CPL - 1 || lam + LPF * c < n) {
+          hp[LPF * c] = (L < 0.0f) ? 1 : 0;
+          if (Lp) Lp[LPF * c] = L;
+        }
+      };
       if (active) {
-        // the next frame was staged a whole frame ago; nothing else of this wave is in flight, so the wait is free
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float yv[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const int j = lam + LPF * c;
-          yv[c] = (j < n) ? (*reinterpret_cast<const float *>(stg + c * 256 + lane * 4) + 0.0f) : 0.0f;
+          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
+          float y = staged(c) + 0.0f;  // -0.0f -> +0.0f
+          if (c == CPL - 1 && lam + LPF * c >= n) y = 0.0f;
+          *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, y);
+          emit(c, cy.x + cy.y);
         }
-        setup(frame, yv);
+        if (er_off != nullptr) {  // cyclic.h:259-262
+          for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
+            const int pos = er[e];
+            if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + 4) = 0.0f;
+          }
+        }
+        if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+        if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
         it = 0;
-      }
+      } else {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int j = lam + LPF * c;
-        if (j < n) {
-          hard[done * n + j] = (Lc[c] < 0.0f) ? 1 : 0;
-          if (Lout) Lout[done * n + j] = Lc[c];
+        for (int c = 0; c < CPL; ++c) {
+          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);
+          emit(c, cy.x + cy.y);
         }
       }
       if (lam == 0) {
@@ -459,6 +581,10 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   // registers a single wave per SIMD spills q to the accumulation registers: still far ahead of the generic kernel)
   constexpr int OCC_S = (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : (2 * K * D + 64 <= 256) ? 2 : 1;
   constexpr int FPW = 64 / LPF;
+  if (!(code->tab.n > static_cast<unsigned>(LPF * (CPL - 1)) && code->tab.n <= static_cast<unsigned>(LPF * CPL))) {
+    set_last_error("minsum_diag: only the last owned column of a lane may lie beyond the frame");
+    return CC_ERR_UNSUPPORTED;
+  }
   const DiagGeometry g{0, 0, PARTIAL ? 1u : static_cast<unsigned>(LPF * D), D, LPF, CPL, SCMS};
   const size_t lds = minsum_diag_lds_bytes(g);
   const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
@@ -470,13 +596,21 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
+  const bool single = p.stop_rule == CC_STOP_AS_SHIPPED || p.iterations == 1;
+#define CC_LAUNCH_S(V, O, S)                                                                                       \
+  {                                                                                                                \
+    e = hipFuncSetAttribute(                                                                                       \
+        reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S>),             \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                                       \
+    if (e == hipSuccess)                                                                                           \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S>), dim3(grid), dim3(256), lds, \
+                         stream, p, code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,    \
+                         d_status, Bq);                                                                            \
+  }
+  // one iteration per frame by construction (stop rule O0, SURVEY F1, or Iterations == 1): the message-free kernel
 #define CC_LAUNCH(V, O)                                                                                            \
   {                                                                                                                \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG>),     \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                    \
-    if (e == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG>), dim3(grid), dim3(256), lds, stream, p, \
-                         code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, Bq);\
+    if (single) CC_LAUNCH_S(V, OCC, true) else CC_LAUNCH_S(V, O, false)                                            \
   }
   switch (p.variant) {
     case CC_ALG_MS: CC_LAUNCH(CC_ALG_MS, OCC) break;
@@ -492,6 +626,7 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
     default: e = hipErrorInvalidValue;
   }
 #undef CC_LAUNCH
+#undef CC_LAUNCH_S
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "minsum_diag kernel launch");
   return CC_OK;
