@@ -106,12 +106,6 @@ const DiagGeometry *diag_geometry(const CodeTables &t);  // nullptr: no diagonal
 std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np = 0, const int *gap = nullptr);
 size_t minsum_diag_lds_bytes(const DiagGeometry &g);
 bool minsum_diag_supported(const cc_code *code);
-int launch_minsum_diag_127(const cc_code *code, const DiagGeometry &g, const MinSumParams &p, const float *d_llr,
-                           const uint16_t *d_er, const uint32_t *d_er_off, uint8_t *d_hard, float *d_L,
-                           uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream);
-int launch_minsum_diag_small(const cc_code *code, const DiagGeometry &g, const MinSumParams &p, const float *d_llr,
-                             const uint16_t *d_er, const uint32_t *d_er_off, uint8_t *d_hard, float *d_L,
-                             uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream);
 std::string minsum_diag_name(const cc_code *code);
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,

@@ -8,34 +8,33 @@
 
 namespace ccamd {
 
-// Geometries with a diagonal instantiation: the row weight must be LPF * D, all D * K messages of a lane live
-// in VGPRs (K * D <= ~170), the syndrome of a frame fits one 32-bit word (K <= 32).
-static const DiagGeometry kDiagGeometries[] = {
-    // n,   k,  w,  D, LPF, CPL, SCMS1/2     (w < LPF * D: the last slot of some lanes is empty, "partial")
-    {255, 24, 112, 7, 16, 16, true},   // BCH(255,231) (paired slots {3, 4, 6} measured slower: profiles/r02_experiments.md E3)
-    {255, 16, 120, 8, 16, 16, true},  // BCH(255,239), partial
-    {255, 32, 124, 8, 16, 16, false}, // BCH(255,223), partial; one wave per SIMD
-    {255, 8, 128, 8, 16, 16, true},    // BCH(255,247)
-    {127, 7, 64, 8, 8, 16, true},      // BCH(127,120)
-    {127, 14, 56, 7, 8, 16, true},    // BCH(127,113)
-    {127, 21, 48, 6, 8, 16, true},    // BCH(127,106)
-    {127, 28, 56, 7, 8, 16, false},   // BCH(127,99): one wave per SIMD, part of the messages in AGPRs
-    {63, 6, 32, 4, 8, 8, true},        // BCH(63,57)
-    {63, 12, 28, 4, 8, 8, true},       // BCH(63,51), partial
-    {63, 18, 24, 3, 8, 8, true},       // BCH(63,45)
-    {63, 24, 28, 4, 8, 8, true},      // BCH(63,39), partial
-    {31, 5, 16, 2, 8, 4, true},        // BCH(31,26)
-    {31, 10, 12, 2, 8, 4, true},       // BCH(31,21), partial
-    {31, 15, 8, 1, 8, 4, true},        // BCH(31,16)
-    {31, 20, 6, 1, 8, 4, true},        // BCH(31,11), partial
-    {15, 4, 8, 1, 8, 2, true},         // BCH(15,11)
-    {15, 8, 4, 1, 8, 2, true},         // BCH(15,7), partial
-    {15, 10, 4, 1, 8, 2, true},        // BCH(15,5), partial
+// Geometries with a diagonal instantiation: minsum_diag_geos.inc, one object file each.
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA)                                                                 \
+  int launch_minsum_diag_##NAME(const cc_code *, const MinSumParams &, const float *, const uint16_t *,              \
+                                const uint32_t *, uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
+#include "minsum_diag_geos.inc"
+#undef GEO
+namespace {
+using DiagLaunch = int (*)(const cc_code *, const MinSumParams &, const float *, const uint16_t *, const uint32_t *,
+                           uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
+struct DiagEntry {
+  DiagGeometry geo;
+  DiagLaunch launch;
 };
-const DiagGeometry *diag_geometry(const CodeTables &t) {
-  for (const DiagGeometry &g : kDiagGeometries)
-    if (t.n == g.n && t.k == g.k && t.row0_support.size() == g.w) return &g;
+const DiagEntry kDiagGeometries[] = {
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA) {{N, KK, W, DD, LL, CC, SC}, &launch_minsum_diag_##NAME},
+#include "minsum_diag_geos.inc"
+#undef GEO
+};
+const DiagEntry *diag_entry(const CodeTables &t) {
+  for (const DiagEntry &e : kDiagGeometries)
+    if (t.n == e.geo.n && t.k == e.geo.k && t.row0_support.size() == e.geo.w) return &e;
   return nullptr;
+}
+}  // namespace
+const DiagGeometry *diag_geometry(const CodeTables &t) {
+  const DiagEntry *e = diag_entry(t);
+  return e ? &e->geo : nullptr;
 }
 
 // Paired deal: np slot pairs (2p, 2p+1) whose diagonals differ by gap[p] in EVERY lane, so that the two columns a
@@ -230,32 +229,9 @@ size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                        size_t B, hipStream_t stream) {
-  const DiagGeometry *g = diag_geometry(code->tab);
-  if (!g) return CC_ERR_UNSUPPORTED;
-  if (g->n <= 63)
-    return launch_minsum_diag_small(code, *g, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
-  if (g->n == 127)
-    return launch_minsum_diag_127(code, *g, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
-#define CC_GEO(KK, DD, LL, CC, OO)                                                                              \
-  if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
-  return launch_diag_geometry<KK, DD, LL, CC, OO>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
-#define CC_GEO_S(KK, DD, LL, CC, OO)                                                                            \
-  if (g->k == KK && g->D == DD && g->LPF == LL && g->CPL == CC)                                                 \
-  return launch_diag_geometry<KK, DD, LL, CC, OO, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream)
-  if (g->w != static_cast<unsigned>(g->LPF * g->D)) {  // partial geometries
-    if (g->k == 16 && g->D == 8 && g->LPF == 16)
-      return launch_diag_geometry<16, 8, 16, 16, 2, true, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,
-                                                                 d_status, B, stream);  // BCH(255,239)
-    if (g->k == 32 && g->D == 8 && g->LPF == 16)
-      return launch_diag_geometry<32, 8, 16, 16, 1, false, true>(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,
-                                                                 d_status, B, stream);  // BCH(255,223)
-    return CC_ERR_UNSUPPORTED;
-  }
-  CC_GEO_S(24, 7, 16, 16, 2);  // BCH(255,231): 168 message registers, two waves per SIMD (one for SCMS1/2)
-  CC_GEO_S(8, 8, 16, 16, 3);  // BCH(255,247), self-correcting variants included (128 message registers)
-#undef CC_GEO
-#undef CC_GEO_S
-  return CC_ERR_UNSUPPORTED;
+  const DiagEntry *e = diag_entry(code->tab);
+  if (!e) return CC_ERR_UNSUPPORTED;
+  return e->launch(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 }
 
 }  // namespace ccamd
