@@ -202,7 +202,8 @@ bool minsum_diag_supported(const cc_code *code) {
   const int alg = code->desc.algorithm;
   const DiagGeometry *geo = diag_geometry(code->tab);
   if (!geo) return false;
-  if (alg == CC_ALG_SCMS1 || alg == CC_ALG_SCMS2) return geo->scms;
+  if (alg == CC_ALG_SCMS1) return true;        // two bits per edge: every geometry
+  if (alg == CC_ALG_SCMS2) return geo->scms;  // q itself: where 2 K D registers fit
   if (alg != CC_ALG_MS && alg != CC_ALG_NMS && alg != CC_ALG_OMS && alg != CC_ALG_2DNMS) return false;
   if (alg == CC_ALG_OMS && !(code->desc.beta >= 0.0)) return false;
   const float a = static_cast<float>(code->desc.alpha);

@@ -158,6 +158,12 @@ __device__ __forceinline__ float med3_abs1(float a1, float q, float a2) {
   return r;
 }
 
+// (acc << 1) | (t == 0.0f) in two instructions: compare into VCC, add with carry
+__device__ __forceinline__ uint32_t shift_in_is_zero(uint32_t acc, float t) {
+  asm("v_cmp_eq_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(t) : "vcc");
+  return acc;
+}
+
 __device__ __forceinline__ int signum(float v) { return (0.0f < v) - (v < 0.0f); }
 // variable-node functor of the self-correcting variants: q = fn(e + y, q_old)
 template <int VARIANT>
@@ -246,8 +252,16 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   // self-correcting variants keep the previous variable->check message of every edge as well (instantiated
   // only where 2 K D registers fit, see kDiagGeometries)
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
-  constexpr bool KEEPQ = NEEDQ && !SINGLE;
+  constexpr bool KEEPQ = VARIANT == CC_ALG_SCMS2 && !SINGLE;
   float Q[KEEPQ ? K : 1][KEEPQ ? D : 1];
+  // SCMS1 (soft_decision.h:261-266) needs two bits of the previous variable->check message of an edge, not the
+  // message: its sign S and whether it was zero Z -- q = (Z or S == sign(t)) ? t : 0 (for t = +-0 both arms are
+  // zero, so signum(t) need not be looked at).  Bit field of row i: D bits at RPW-row words, edge d at bit
+  // D - 1 - d of the field (the order v_alignbit / v_addc shift them in); updated in place row by row.
+  constexpr bool BITS1 = VARIANT == CC_ALG_SCMS1 && !SINGLE;
+  constexpr int RPW = 32 / D;                  // rows per 32-bit word
+  constexpr int NW = (K + RPW - 1) / RPW;      // words per lane
+  uint32_t SW[BITS1 ? NW : 1], ZW[BITS1 ? NW : 1];
 
   // Asynchronous copy of frame f's channel values into STG, no VGPR on the way.  EXEC is the caller's: the lanes of
   // one group, or of several groups that finish in the same iteration -- so nothing here may depend on the group.
@@ -332,6 +346,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     }
     if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
     if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+    if constexpr (BITS1) static_for<NW>([&](auto Wd) { SW[Wd] = 0u; ZW[Wd] = 0xFFFFFFFFu; });  // q_old = 0 everywhere
   };
 
   // first frame of every group: staged like all the others, then the one after it
@@ -348,15 +363,23 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // ---------------- one min-sum iteration for the four resident frames ----------------
     // software pipeline over rows: the {cs, y} operands of row i+1 are fetched from LDS before row i is
     // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
+    // (SCMS1 on a geometry that already fills the register file fetches a row's operands when the row starts:
+    //  the bit words below take the 14 registers the prefetch would hold)
+    constexpr bool PREFETCH = !(BITS1 && K * D >= 160);
     float2 cyq[D];
-    static_for<D>([&](auto DD) {
-      constexpr int d = DD;
-      const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * slot_gap<PG>(d);
-      if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
-      else cyq[d] = *reinterpret_cast<const float2 *>(a);
-    });
+    auto fetch = [&](auto IC) {
+      constexpr int row = decltype(IC)::value;
+      static_for<D>([&](auto DD) {
+        constexpr int d = DD;
+        const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d));
+        if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
+        else cyq[d] = *reinterpret_cast<const float2 *>(a);
+      });
+    };
+    if constexpr (PREFETCH) fetch(std::integral_constant<int, 0>{});
     static_for<K>([&](auto IR) {
       constexpr int i = IR;
+      if constexpr (!PREFETCH) fetch(IR);
       // q, then r, of this row's edges: the message registers, or temporaries when nothing is kept
       // (accessors with literal indices: a reference to R[i] would keep the whole array out of registers)
       float Tloc[D];
@@ -375,17 +398,39 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         float a1 = 0.0f, a2 = (D == 1) ? 3.402823466e+38f : 0.0f;
         uint32_t s = 0;
         uint32_t qs[D];
+        // SCMS1: all t = e + y of the row first, their sign / zero bits shifted into two words, ONE three-input bit
+        // operation for the keep decision of the whole row, then an arithmetic bit-field extract + AND per edge
+        uint32_t keep = 0;
+        constexpr int wi = BITS1 ? i / RPW : 0, sh = BITS1 ? (i % RPW) * D : 0;
+        if constexpr (BITS1) {
+          uint32_t tw = 0, tz = 0;
+          static_for<D>([&](auto DD) {
+            constexpr int d = DD;
+            const float t = (cyq[d].x - R[i][d]) + cyq[d].y;  // soft_decision.h:135-136
+            R[i][d] = t;
+            tw = __builtin_amdgcn_alignbit(tw, f2u(t), 31);  // (tw << 1) | sign(t)
+            tz = shift_in_is_zero(tz, t);
+          });
+          constexpr uint32_t field = ((D == 32 ? 0u : (1u << D)) - 1u) << sh;
+          const uint32_t tws = tw << sh, tzs = tz << sh;
+          keep = ZW[wi] | ~(SW[wi] ^ tws);                       // Z or signs agree (bits outside the field: unused)
+          SW[wi] = (SW[wi] & ~field) | (tws & keep);             // sign of the new q (a dropped q is +0)
+          ZW[wi] = (ZW[wi] & ~field) | ((~keep & field) | tzs);  // new q is zero: dropped, or t itself was
+        }
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
           float q;
-          if constexpr (SINGLE) {
+          if constexpr (BITS1) {
+            const int32_t m = __builtin_amdgcn_sbfe(static_cast<int32_t>(keep), sh + D - 1 - d, 1);  // 0 or ~0
+            q = u2f(f2u(R[i][d]) & static_cast<uint32_t>(m));
+          } else if constexpr (SINGLE) {
             q = cyq[d].y;
             if constexpr (NEEDQ) q = self_correct<VARIANT>(q, 0.0f);
           } else {
             float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
             if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
             q = e + cyq[d].y;                                                   // :136,:207-209
-            if constexpr (NEEDQ) {
+            if constexpr (KEEPQ) {
               q = self_correct<VARIANT>(q, Q[i][d]);
               Q[i][d] = q;
             }
@@ -398,7 +443,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             qb &= sgn_keep;
           }
           qs[d] = qb;
-          if constexpr (SINGLE && !PARTIAL && D >= 2) {  // q is a loaded value here: see min_abs2
+          if constexpr ((SINGLE || BITS1) && !PARTIAL && D >= 2) {  // q is a loaded / masked value here: see min_abs2
             if constexpr (d == 0) {
               a1 = q;  // |.| taken by the first use
             } else if constexpr (d == 1) {
@@ -429,13 +474,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         m2[0] = f2u(a2);
         sg[0] = s;
       }
-      if constexpr (i + 1 < K)  // prefetch the next row's operands
-        static_for<D>([&](auto DD) {
-          constexpr int d = DD;
-          const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * (i + 1 + slot_gap<PG>(d));
-          if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
-          else cyq[d] = *reinterpret_cast<const float2 *>(a);
-        });
+      if constexpr (PREFETCH && i + 1 < K) fetch(std::integral_constant<int, i + 1>{});  // the next row's operands
       float cn[D];
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
@@ -446,7 +485,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       // undoes the DPP form of that stage (a bit operation with three inputs takes no DPP operand)
       asm volatile("" : "+v"(sg[0]));
       const uint32_t sign31 = sg[0] & 0x80000000u;
-      if constexpr (VARIANT == CC_ALG_MS) {
+      if constexpr (VARIANT == CC_ALG_MS || VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2) {  // h(m) = m
         // exclusive minimum with the exclusive sign in TWO instructions per edge: u = med3(q, -m2, m2) is
         // sign(q) min(|q|, m2), i.e. +-m1 for the holder of the minimum and +-m2 for everybody else (|q| >= m2);
         // XOR with m1 ^ m2 swaps the two magnitudes, XOR with the row parity (bit 31) turns sign(q) into the
@@ -548,6 +587,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         }
         if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
         if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+        if constexpr (BITS1) static_for<NW>([&](auto Wd) { SW[Wd] = 0u; ZW[Wd] = 0xFFFFFFFFu; });
         it = 0;
       } else {
 #pragma unroll
@@ -589,8 +629,8 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   const size_t lds = minsum_diag_lds_bytes(g);
   const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
   unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
-  const bool scms_variant = p.variant == CC_ALG_SCMS1 || p.variant == CC_ALG_SCMS2;
-  const unsigned long long occ = scms_variant ? static_cast<unsigned long long>(OCC_S) : OCC;
+  // SCMS2 keeps q in K D more registers (OCC_S); SCMS1 keeps two bits per edge and runs at the occupancy of plain MS
+  const unsigned long long occ = p.variant == CC_ALG_SCMS2 ? static_cast<unsigned long long>(OCC_S) : OCC;
   if (per_cu > occ) per_cu = occ;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
@@ -618,7 +658,7 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
     case CC_ALG_OMS: CC_LAUNCH(CC_ALG_OMS, OCC) break;
     case CC_ALG_2DNMS: CC_LAUNCH(CC_ALG_2DNMS, OCC) break;
     case CC_ALG_SCMS1:
-      if constexpr (SCMS) CC_LAUNCH(CC_ALG_SCMS1, OCC_S) else e = hipErrorInvalidValue;
+      CC_LAUNCH(CC_ALG_SCMS1, OCC)
       break;
     case CC_ALG_SCMS2:
       if constexpr (SCMS) CC_LAUNCH(CC_ALG_SCMS2, OCC_S) else e = hipErrorInvalidValue;
