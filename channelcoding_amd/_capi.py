@@ -65,8 +65,8 @@ _SIGNATURES = {
     "cc_encode_batch_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_correct_hard_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
     "cc_correct_hard_batch_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
-    "cc_correct_hard_f32_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_size_t]),
-    "cc_correct_hard_f32_batch_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "cc_correct_hard_f32_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
+    "cc_correct_hard_f32_batch_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_correct_soft_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
     "cc_correct_soft_batch_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_extract_batch": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),

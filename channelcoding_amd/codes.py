@@ -316,11 +316,9 @@ class cyclic:
             return res
         nerr = np.zeros(B, np.int32)
         if signed:
-            if er is not None:
-                raise CcError(capi.ERR_UNSUPPORTED, "erasures with a signed input sequence")
             y = np.ascontiguousarray(b, np.float32).reshape(B, self.n)
-            capi.check(lib.cc_correct_hard_f32_batch(self._h, _ptr(y), _ptr(out), _ptr(nerr), _ptr(status), B),
-                       "cc_correct_hard_f32_batch")
+            capi.check(lib.cc_correct_hard_f32_batch(self._h, _ptr(y), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
+                                                     _ptr(status), B), "cc_correct_hard_f32_batch")
         else:
             sym = np.ascontiguousarray(b, np.uint8).reshape(B, self.n)
             capi.check(lib.cc_correct_hard_batch(self._h, _ptr(sym), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
@@ -339,6 +337,8 @@ class cyclic:
         if erasures is not None:
             ev, eo = _erasure_csr(erasures, B, self.n)
             if ev is not None:
+                if ev.size == 0:  # an empty tensor has a null data pointer: keep the list addressable
+                    ev = np.zeros(1, ev.dtype)
                 er = torch.from_numpy(ev.astype(np.int16)).to(dev)
                 off = torch.from_numpy(eo.astype(np.int32)).to(dev)
         out = torch.empty((B, self.n), dtype=torch.uint8, device=dev)
@@ -357,8 +357,8 @@ class cyclic:
             return res
         nerr = torch.empty(B, dtype=torch.int32, device=dev)
         if b.dtype == torch.float32:
-            capi.check(lib.cc_correct_hard_f32_batch_dev(self._h, _ptr(b), _ptr(out), _ptr(nerr), _ptr(status), B, st),
-                       "cc_correct_hard_f32_batch_dev")
+            capi.check(lib.cc_correct_hard_f32_batch_dev(self._h, _ptr(b), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
+                                                         _ptr(status), B, st), "cc_correct_hard_f32_batch_dev")
         elif b.dtype == torch.uint8:
             capi.check(lib.cc_correct_hard_batch_dev(self._h, _ptr(b), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
                                                      _ptr(status), B, st), "cc_correct_hard_batch_dev")

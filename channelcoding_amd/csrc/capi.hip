@@ -38,14 +38,104 @@ struct DeviceGuard {
   }
 };
 
-template <typename T>
-struct DevBuf {
-  T *p = nullptr;
-  hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 16); }
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+}  // namespace (anonymous)
+// Staging of the host-pointer entry points ("no hidden allocation per call; thread-safe per
+// stream").  Owned by the handle, created on first use: two private streams and, per stream, grow-only device
+// buffers.  A host-pointer call cuts the batch into chunks that alternate between the two streams -- the upload of
+// chunk k + 1 overlaps the kernel and the download of chunk k -- and waits for ITS streams only
+// (hipStreamSynchronize, never hipDeviceSynchronize: other streams of the caller keep running).  Calls on one
+// handle are serialised by `lock`; different handles are independent.
+struct HostStage {
+  std::mutex lock;
+  hipStream_t stream[2] = {nullptr, nullptr};
+  struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  Buf buf[2][8];
+  int init() {
+    for (hipStream_t &s : stream)
+      if (!s) CC_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return CC_OK;
+  }
+  template <typename T>
+  int get(int slot, int idx, size_t count, T **out) {  // grow-only; contents are not preserved
+    Buf &b = buf[slot][idx];
+    const size_t bytes = count * sizeof(T) + 16;
+    if (bytes > b.cap) {
+      CC_HIP_TRY(hipStreamSynchronize(stream[slot]));
+      if (b.p) (void)hipFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      const size_t want = bytes + bytes / 4;  // grow by 25 % so that slowly growing batches do not reallocate each time
+      CC_HIP_TRY(hipMalloc(&b.p, want));
+      b.cap = want;
+    }
+    *out = static_cast<T *>(b.p);
+    return CC_OK;
+  }
+  int drain() {
+    for (hipStream_t s : stream)
+      if (s) CC_HIP_TRY(hipStreamSynchronize(s));
+    return CC_OK;
   }
 };
+void host_stage_free(HostStage *st) {
+  if (!st) return;
+  for (int slot = 0; slot < 2; ++slot) {
+    if (st->stream[slot]) (void)hipStreamSynchronize(st->stream[slot]);
+    for (HostStage::Buf &b : st->buf[slot])
+      if (b.p) (void)hipFree(b.p);
+    if (st->stream[slot]) (void)hipStreamDestroy(st->stream[slot]);
+  }
+  delete st;
+}
+namespace {
+
+// the handle's staging object (created on first use) with its lock held for the duration of one host-pointer call
+struct StageLock {
+  HostStage *st = nullptr;
+  std::unique_lock<std::mutex> held;
+  int rc = CC_OK;
+  explicit StageLock(const cc_code *code) {
+    {
+      std::lock_guard<std::mutex> g(code->lazy_lock);
+      if (!code->stage) code->stage = new HostStage();
+      st = code->stage;
+    }
+    held = std::unique_lock<std::mutex>(st->lock);
+    rc = st->init();
+  }
+};
+// frames per chunk: about 32 MiB of the widest per-frame stream, at least 16 frames
+size_t chunk_frames(size_t bytes_per_frame, size_t B) {
+  static const size_t chunk_bytes = [] {  // CC_AMD_HOST_CHUNK_BYTES: tests force many small chunks
+    const char *e = std::getenv("CC_AMD_HOST_CHUNK_BYTES");
+    const long long v = e ? std::atoll(e) : 0;
+    return v > 0 ? static_cast<size_t>(v) : static_cast<size_t>(32u << 20);
+  }();
+  size_t ch = chunk_bytes / (bytes_per_frame ? bytes_per_frame : 1);
+  if (ch < 16) ch = 16;
+  return ch < B ? ch : B;
+}
+// uploads the erasure lists of frames [c0, c0 + m) and returns device pointers with which the kernels index them
+// by the GLOBAL offsets: d_er is shifted back by off[c0] elements (only [off[c0], off[c0 + m]) is ever read)
+int upload_erasures(HostStage &st, int slot, int idx, const uint16_t *erasures, const uint32_t *offsets, size_t c0,
+                    size_t m, const uint16_t **d_er, const uint32_t **d_off) {
+  *d_er = nullptr;
+  *d_off = nullptr;
+  if (!erasures) return CC_OK;
+  const size_t e0 = offsets[c0], ne = offsets[c0 + m] - e0;
+  uint16_t *er = nullptr;
+  uint32_t *off = nullptr;
+  if (int rc = st.get(slot, idx, ne + 1, &er)) return rc;
+  if (int rc = st.get(slot, idx + 1, m + 1, &off)) return rc;
+  if (ne) CC_HIP_TRY(hipMemcpyAsync(er, erasures + e0, ne * sizeof(uint16_t), hipMemcpyHostToDevice, st.stream[slot]));
+  CC_HIP_TRY(hipMemcpyAsync(off, offsets + c0, (m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st.stream[slot]));
+  *d_er = er - e0;
+  *d_off = off;
+  return CC_OK;
+}
 
 bool is_soft(int alg) { return alg >= CC_ALG_MS && alg <= CC_ALG_2DNMS; }
 bool is_hard(int alg) { return alg >= CC_ALG_PGZ && alg <= CC_ALG_EUKLID; }
@@ -333,6 +423,7 @@ void cc_code_destroy(cc_code *code) {
     if (code->d_colbits) (void)hipFree(code->d_colbits);
     if (code->d_parity) (void)hipFree(code->d_parity);
     if (code->mc) mc_workspace_free(code->mc);
+    if (code->stage) host_stage_free(code->stage);
     if (code->d_alg) (void)hipFree(code->d_alg);
   }
   delete code;
@@ -398,38 +489,50 @@ int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t 
                           size_t B) {
   if (!code || (B && (!llr || !hard))) return CC_ERR_INVALID_ARGUMENT;
   if ((erasures == nullptr) != (erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  if (!code->soft) {
+    set_last_error("code was created with a hard-decision algorithm; use cc_correct_hard_f32_batch");
+    return CC_ERR_INVALID_ARGUMENT;
+  }
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   if (B == 0) return CC_OK;
-  DeviceGuard guard(code->device);
   const size_t n = code->tab.n;
-  DevBuf<float> d_llr, d_L;
-  DevBuf<uint8_t> d_hard;
-  DevBuf<uint16_t> d_iters, d_er;
-  DevBuf<uint32_t> d_off;
-  DevBuf<int32_t> d_status;
-  CC_HIP_TRY(d_llr.alloc(B * n));
-  CC_HIP_TRY(d_hard.alloc(B * n));
-  CC_HIP_TRY(d_iters.alloc(B));
-  CC_HIP_TRY(d_status.alloc(B));
-  if (L) CC_HIP_TRY(d_L.alloc(B * n));
-  CC_HIP_TRY(hipMemcpy(d_llr.p, llr, B * n * sizeof(float), hipMemcpyHostToDevice));
   if (erasures) {
     const size_t ne = erasure_offsets[B];
     for (size_t e = 0; e < ne; ++e)
       if (erasures[e] >= n) return CC_ERR_INVALID_ARGUMENT;  // copy.at(erasure) would throw, cyclic.h:261
-    CC_HIP_TRY(d_er.alloc(ne + 1));
-    CC_HIP_TRY(d_off.alloc(B + 1));
-    if (ne) CC_HIP_TRY(hipMemcpy(d_er.p, erasures, ne * sizeof(uint16_t), hipMemcpyHostToDevice));
-    CC_HIP_TRY(hipMemcpy(d_off.p, erasure_offsets, (B + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  int rc = cc_correct_soft_batch_dev(code, d_llr.p, d_er.p, d_off.p, d_hard.p, d_L.p, d_iters.p, d_status.p, B, nullptr);
-  if (rc != CC_OK) return rc;
-  CC_HIP_TRY(hipDeviceSynchronize());
-  CC_HIP_TRY(hipMemcpy(hard, d_hard.p, B * n, hipMemcpyDeviceToHost));
-  if (L) CC_HIP_TRY(hipMemcpy(L, d_L.p, B * n * sizeof(float), hipMemcpyDeviceToHost));
-  if (iters) CC_HIP_TRY(hipMemcpy(iters, d_iters.p, B * sizeof(uint16_t), hipMemcpyDeviceToHost));
-  if (status) CC_HIP_TRY(hipMemcpy(status, d_status.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-  return CC_OK;
+  DeviceGuard guard(code->device);
+  StageLock sl(code);
+  if (sl.rc != CC_OK) return sl.rc;
+  HostStage &st = *sl.st;
+  const size_t CH = chunk_frames(n * sizeof(float), B);
+  size_t k = 0;
+  for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
+    const int slot = static_cast<int>(k & 1);
+    const size_t m = B - c0 < CH ? B - c0 : CH;
+    hipStream_t s = st.stream[slot];
+    CC_HIP_TRY(hipStreamSynchronize(s));  // the chunk that used this slot's buffers two turns ago is home
+    float *d_llr = nullptr, *d_L = nullptr;
+    uint8_t *d_hard = nullptr;
+    uint16_t *d_iters = nullptr;
+    int32_t *d_status = nullptr;
+    const uint16_t *d_er = nullptr;
+    const uint32_t *d_off = nullptr;
+    if (int rc = st.get(slot, 0, m * n, &d_llr)) return rc;
+    if (int rc = st.get(slot, 1, m * n, &d_hard)) return rc;
+    if (int rc = st.get(slot, 2, m, &d_iters)) return rc;
+    if (int rc = st.get(slot, 3, m, &d_status)) return rc;
+    if (L)
+      if (int rc = st.get(slot, 4, m * n, &d_L)) return rc;
+    CC_HIP_TRY(hipMemcpyAsync(d_llr, llr + c0 * n, m * n * sizeof(float), hipMemcpyHostToDevice, s));
+    if (int rc = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return rc;
+    if (int rc = launch_minsum(code, d_llr, d_er, d_off, d_hard, d_L, d_iters, d_status, m, s)) return rc;
+    CC_HIP_TRY(hipMemcpyAsync(hard + c0 * n, d_hard, m * n, hipMemcpyDeviceToHost, s));
+    if (L) CC_HIP_TRY(hipMemcpyAsync(L + c0 * n, d_L, m * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (iters) CC_HIP_TRY(hipMemcpyAsync(iters + c0, d_iters, m * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+  return st.drain();
 }
 
 
@@ -481,14 +584,41 @@ int cc_correct_hard_batch_dev(const cc_code *code, const uint8_t *d_in, const ui
                           static_cast<hipStream_t>(stream));
 }
 
-int cc_correct_hard_f32_batch_dev(const cc_code *code, const float *d_in, uint8_t *d_out, int32_t *d_nerr,
+// bit = (x < 0) of a soft value (cyclic.h:163-184) as a byte: the Peterson-Gorenstein-Zierler erasure rule of
+// bch.h:97-149 re-decodes the word with the erased positions forced to 0 and to 1, on symbols
+static __global__ void sign_bytes_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, unsigned long long count) {
+  for (unsigned long long i = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x; i < count;
+       i += static_cast<unsigned long long>(gridDim.x) * blockDim.x)
+    out[i] = in[i] < 0.0f ? 1 : 0;
+}
+
+// hard decoding of device-resident words; float input + PGZ + erasures goes through a byte image of the signs
+static int hard_dev(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er, const uint32_t *d_off,
+                    uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream) {
+  if (!(d_er && code->desc.algorithm == CC_ALG_PGZ))
+    return launch_algebraic(code, float_in, d_in, d_er, d_off, d_out, d_nerr, d_status, B, stream);
+  if (!float_in)
+    return launch_pgz_erasures(code, static_cast<const uint8_t *>(d_in), d_er, d_off, d_out, d_nerr, d_status, B, stream);
+  uint8_t *bytes = nullptr;
+  const size_t count = B * code->tab.n;
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&bytes), count + 16, stream));
+  hipLaunchKernelGGL(sign_bytes_kernel, dim3(code->num_cus * 8), dim3(256), 0, stream, static_cast<const float *>(d_in),
+                     bytes, static_cast<unsigned long long>(count));
+  const int rc = launch_pgz_erasures(code, bytes, d_er, d_off, d_out, d_nerr, d_status, B, stream);
+  (void)hipFreeAsync(bytes, stream);
+  return rc;
+}
+
+int cc_correct_hard_f32_batch_dev(const cc_code *code, const float *d_in, const uint16_t *d_erasures,
+                                  const uint32_t *d_erasure_offsets, uint8_t *d_out, int32_t *d_nerr,
                                   int32_t *d_status, size_t B, void *stream) {
   if (!code || (B && (!d_in || !d_out))) return CC_ERR_INVALID_ARGUMENT;
-  const int rc = hard_supported(code, false);
+  if ((d_erasures == nullptr) != (d_erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  const int rc = hard_supported(code, d_erasures != nullptr);
   if (rc != CC_OK) return rc;
   DeviceGuard guard(code->device);
-  return launch_algebraic(code, true, d_in, nullptr, nullptr, d_out, d_nerr, d_status, B,
-                          static_cast<hipStream_t>(stream));
+  return hard_dev(code, true, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
+                  static_cast<hipStream_t>(stream));
 }
 
 static int hard_host(const cc_code *code, bool float_in, const void *in, const uint16_t *erasures,
@@ -505,35 +635,39 @@ static int hard_host(const cc_code *code, bool float_in, const void *in, const u
     for (size_t i = 0; i < B * n; ++i)
       if (b[i] & mask) return CC_ERR_NOT_IN_FIELD;
   }
-  DeviceGuard guard(code->device);
-  const size_t esz = float_in ? sizeof(float) : 1;
-  DevBuf<uint8_t> d_in, d_out;
-  DevBuf<uint16_t> d_er;
-  DevBuf<uint32_t> d_off;
-  DevBuf<int32_t> d_nerr, d_status;
-  CC_HIP_TRY(d_in.alloc(B * n * esz));
-  CC_HIP_TRY(d_out.alloc(B * n));
-  CC_HIP_TRY(d_nerr.alloc(B));
-  CC_HIP_TRY(d_status.alloc(B));
-  CC_HIP_TRY(hipMemcpy(d_in.p, in, B * n * esz, hipMemcpyHostToDevice));
   if (erasures) {
     const size_t ne = erasure_offsets[B];
     for (size_t e = 0; e < ne; ++e)
       if (erasures[e] >= n) return CC_ERR_INVALID_ARGUMENT;
-    CC_HIP_TRY(d_er.alloc(ne + 1));
-    CC_HIP_TRY(d_off.alloc(B + 1));
-    if (ne) CC_HIP_TRY(hipMemcpy(d_er.p, erasures, ne * sizeof(uint16_t), hipMemcpyHostToDevice));
-    CC_HIP_TRY(hipMemcpy(d_off.p, erasure_offsets, (B + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  const int lrc = (erasures && code->desc.algorithm == CC_ALG_PGZ && !float_in)
-                      ? launch_pgz_erasures(code, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr)
-                      : launch_algebraic(code, float_in, d_in.p, d_er.p, d_off.p, d_out.p, d_nerr.p, d_status.p, B, nullptr);
-  if (lrc != CC_OK) return lrc;
-  CC_HIP_TRY(hipDeviceSynchronize());
-  CC_HIP_TRY(hipMemcpy(out, d_out.p, B * n, hipMemcpyDeviceToHost));
-  if (nerr) CC_HIP_TRY(hipMemcpy(nerr, d_nerr.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (status) CC_HIP_TRY(hipMemcpy(status, d_status.p, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-  return CC_OK;
+  DeviceGuard guard(code->device);
+  StageLock sl(code);
+  if (sl.rc != CC_OK) return sl.rc;
+  HostStage &st = *sl.st;
+  const size_t esz = float_in ? sizeof(float) : 1;
+  const size_t CH = chunk_frames(n * esz, B);
+  size_t k = 0;
+  for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
+    const int slot = static_cast<int>(k & 1);
+    const size_t m = B - c0 < CH ? B - c0 : CH;
+    hipStream_t s = st.stream[slot];
+    CC_HIP_TRY(hipStreamSynchronize(s));
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    int32_t *d_nerr = nullptr, *d_status = nullptr;
+    const uint16_t *d_er = nullptr;
+    const uint32_t *d_off = nullptr;
+    if (int r = st.get(slot, 0, m * n * esz, &d_in)) return r;
+    if (int r = st.get(slot, 1, m * n, &d_out)) return r;
+    if (int r = st.get(slot, 2, m, &d_nerr)) return r;
+    if (int r = st.get(slot, 3, m, &d_status)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(d_in, static_cast<const uint8_t *>(in) + c0 * n * esz, m * n * esz, hipMemcpyHostToDevice, s));
+    if (int r = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return r;
+    if (int r = hard_dev(code, float_in, d_in, d_er, d_off, d_out, d_nerr, d_status, m, s)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(out + c0 * n, d_out, m * n, hipMemcpyDeviceToHost, s));
+    if (nerr) CC_HIP_TRY(hipMemcpyAsync(nerr + c0, d_nerr, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+  return st.drain();
 }
 
 int cc_correct_hard_batch(const cc_code *code, const uint8_t *in, const uint16_t *erasures,
@@ -541,9 +675,9 @@ int cc_correct_hard_batch(const cc_code *code, const uint8_t *in, const uint16_t
   return hard_host(code, false, in, erasures, erasure_offsets, out, nerr, status, B);
 }
 
-int cc_correct_hard_f32_batch(const cc_code *code, const float *in, uint8_t *out, int32_t *nerr, int32_t *status,
-                              size_t B) {
-  return hard_host(code, true, in, nullptr, nullptr, out, nerr, status, B);
+int cc_correct_hard_f32_batch(const cc_code *code, const float *in, const uint16_t *erasures,
+                              const uint32_t *erasure_offsets, uint8_t *out, int32_t *nerr, int32_t *status, size_t B) {
+  return hard_host(code, true, in, erasures, erasure_offsets, out, nerr, status, B);
 }
 
 /* ------------------------------ encode / extract ------------------------------ */
@@ -577,15 +711,25 @@ static int byte_map_host(const cc_code *code, bool encode, const uint8_t *src, u
       if (src[i] & mask) return CC_ERR_NOT_IN_FIELD;
   }
   DeviceGuard guard(code->device);
-  DevBuf<uint8_t> d_src, d_dst;
-  CC_HIP_TRY(d_src.alloc(B * in_w));
-  CC_HIP_TRY(d_dst.alloc(B * out_w));
-  CC_HIP_TRY(hipMemcpy(d_src.p, src, B * in_w, hipMemcpyHostToDevice));
-  const int rc = encode ? launch_encode(code, d_src.p, d_dst.p, B, nullptr) : launch_extract(code, d_src.p, d_dst.p, B, nullptr);
-  if (rc != CC_OK) return rc;
-  CC_HIP_TRY(hipDeviceSynchronize());
-  CC_HIP_TRY(hipMemcpy(dst, d_dst.p, B * out_w, hipMemcpyDeviceToHost));
-  return CC_OK;
+  StageLock sl(code);
+  if (sl.rc != CC_OK) return sl.rc;
+  HostStage &st = *sl.st;
+  const size_t CH = chunk_frames(n, B);
+  size_t k = 0;
+  for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
+    const int slot = static_cast<int>(k & 1);
+    const size_t m = B - c0 < CH ? B - c0 : CH;
+    hipStream_t s = st.stream[slot];
+    CC_HIP_TRY(hipStreamSynchronize(s));
+    uint8_t *d_src = nullptr, *d_dst = nullptr;
+    if (int r = st.get(slot, 0, m * in_w, &d_src)) return r;
+    if (int r = st.get(slot, 1, m * out_w, &d_dst)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(d_src, src + c0 * in_w, m * in_w, hipMemcpyHostToDevice, s));
+    const int rc = encode ? launch_encode(code, d_src, d_dst, m, s) : launch_extract(code, d_src, d_dst, m, s);
+    if (rc != CC_OK) return rc;
+    CC_HIP_TRY(hipMemcpyAsync(dst + c0 * out_w, d_dst, m * out_w, hipMemcpyDeviceToHost, s));
+  }
+  return st.drain();
 }
 
 int cc_encode_batch(const cc_code *code, const uint8_t *msg, uint8_t *cw, size_t B) {
@@ -617,8 +761,7 @@ static int decode_host(const cc_code *code, bool float_in, const void *in, const
     rc = cc_correct_soft_batch(code, static_cast<const float *>(in), erasures, erasure_offsets, words, nullptr, iters,
                                status, B);
   } else if (float_in) {
-    if (erasures) return CC_ERR_UNSUPPORTED;
-    rc = cc_correct_hard_f32_batch(code, static_cast<const float *>(in), words, nerr, status, B);
+    rc = cc_correct_hard_f32_batch(code, static_cast<const float *>(in), erasures, erasure_offsets, words, nerr, status, B);
   } else {
     rc = cc_correct_hard_batch(code, static_cast<const uint8_t *>(in), erasures, erasure_offsets, words, nerr, status, B);
   }

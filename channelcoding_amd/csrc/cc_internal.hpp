@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct AlgebraicTables {
 namespace ccamd {
 struct McWorkspace;
 void mc_workspace_free(McWorkspace *w);
+struct HostStage;  // capi.hip: staging of the host-pointer entry points (private streams, grow-only device buffers)
+void host_stage_free(HostStage *s);
 }  // namespace ccamd
 
 struct cc_code {
@@ -69,6 +72,8 @@ struct cc_code {
   ccamd::AlgebraicTables *d_alg = nullptr;
   ccamd::AlgebraicTables h_alg;
   mutable ccamd::McWorkspace *mc = nullptr;  // lazily allocated Monte-Carlo chunk buffers
+  mutable ccamd::HostStage *stage = nullptr;  // lazily allocated staging of the host-pointer entry points
+  mutable std::mutex lazy_lock;               // guards the creation of the two above
   int num_cus = 256;
   bool force_generic = false;  // CC_AMD_FORCE_GENERIC=1: A/B the generic kernel against the fast one
   std::string name;

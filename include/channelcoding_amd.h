@@ -161,10 +161,12 @@ int cc_correct_hard_batch(const cc_code *code, const uint8_t *in /* B*n symbols 
 int cc_correct_hard_batch_dev(const cc_code *code, const uint8_t *d_in, const uint16_t *d_erasures,
                               const uint32_t *d_erasure_offsets, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status,
                               size_t B, void *stream);
-/* signed input sequence (cyclic.h:163-173): bit = (x < 0), then as above */
-int cc_correct_hard_f32_batch(const cc_code *code, const float *in /* B*n */, uint8_t *out, int32_t *nerr,
-                              int32_t *status, size_t B);
-int cc_correct_hard_f32_batch_dev(const cc_code *code, const float *d_in, uint8_t *d_out, int32_t *d_nerr,
+/* signed input sequence (cyclic.h:163-173): bit = (x < 0), then as above -- erasures included: the reference's
+ * correct_ takes them for any InputSequence (cyclic.h:207-252, bch.h:97-149) */
+int cc_correct_hard_f32_batch(const cc_code *code, const float *in /* B*n */, const uint16_t *erasures,
+                              const uint32_t *erasure_offsets, uint8_t *out, int32_t *nerr, int32_t *status, size_t B);
+int cc_correct_hard_f32_batch_dev(const cc_code *code, const float *d_in, const uint16_t *d_erasures,
+                                  const uint32_t *d_erasure_offsets, uint8_t *d_out, int32_t *d_nerr,
                                   int32_t *d_status, size_t B, void *stream);
 
 /* ---- soft-decision correct: cyclic::correct_(soft_decision_tag) cyclic.h:254-267 -> min_sum

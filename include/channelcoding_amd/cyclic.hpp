@@ -369,7 +369,8 @@ public:
                     "cc_correct_soft_batch");
     } else {
       r.nerr.resize(B);
-      detail::check(cc_correct_hard_f32_batch(handle.get(), values, r.words.data(), r.nerr.data(), r.status.data(), B),
+      detail::check(cc_correct_hard_f32_batch(handle.get(), values, nullptr, nullptr, r.words.data(), r.nerr.data(),
+                                              r.status.data(), B),
                     "cc_correct_hard_f32_batch");
     }
     return r;
@@ -423,8 +424,7 @@ private:
       if (soft) {
         rc = cc_correct_soft_batch(handle.get(), y.data(), erp, offp, out.data(), nullptr, nullptr, &status, 1);
       } else {
-        if (erp) throw std::runtime_error("erasures with a signed input sequence are not supported on the device path");
-        rc = cc_correct_hard_f32_batch(handle.get(), y.data(), out.data(), &nerr, &status, 1);
+        rc = cc_correct_hard_f32_batch(handle.get(), y.data(), erp, offp, out.data(), &nerr, &status, 1);
       }
     } else {
       if (soft) throw std::runtime_error("min-sum needs a signed (soft) input sequence");
