@@ -80,13 +80,16 @@ random_bits_kernel(uint8_t *__restrict__ msg, int l, int group_log2, unsigned lo
 // frame from Philox counter (frame, q): no division by n anywhere, 16-byte stores except for a ragged tail.
 __global__ void __launch_bounds__(256)
 awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, int group_log2,
-            unsigned long long first_frame, unsigned long long frames, float sigma, uint32_t k0, uint32_t k1) {
+            unsigned long long first_frame, unsigned long long frames, float sigma, uint32_t k0, uint32_t k1,
+            unsigned long long *__restrict__ counters) {
   const int G = 1 << group_log2;
   const unsigned long long tid = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const unsigned long long stride = (static_cast<unsigned long long>(gridDim.x) * blockDim.x) >> group_log2;
   const int qd = static_cast<int>(tid & static_cast<unsigned long long>(G - 1));
-  if (4 * qd >= n) return;
-  for (unsigned long long f = tid >> group_log2; f < frames; f += stride) {
+  // channel bit errors (hard decision of y differs from the bit sent) are counted where y is made: the counting
+  // kernel then never reads the channel values again.  One 64-bit atomic per wavefront at the end.
+  unsigned cherr = 0;
+  for (unsigned long long f = tid >> group_log2; 4 * qd < n && f < frames; f += stride) {
     const unsigned long long gf = first_frame + f;
     const Philox p = philox4x32_10(static_cast<uint32_t>(gf), static_cast<uint32_t>(gf >> 32), qd, 0u, k0, k1);
     float z[4];
@@ -97,15 +100,29 @@ awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, in
     if (4 * qd + 4 <= n) {
       float x[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) x[s] = ((src && src[s]) ? -1.0f : 1.0f) + sigma * z[s];  // BPSK 0 -> +1
+      for (int s = 0; s < 4; ++s) {
+        const bool one = src && src[s];
+        x[s] = (one ? -1.0f : 1.0f) + sigma * z[s];  // BPSK 0 -> +1
+        cherr += (x[s] < 0.0f) != one;
+      }
       // frames are n floats apart, so dst is 4-byte aligned only: four dword stores the compiler may merge
       dst[0] = x[0];
       dst[1] = x[1];
       dst[2] = x[2];
       dst[3] = x[3];
     } else {
-      for (int s = 0; 4 * qd + s < n; ++s) dst[s] = ((src && src[s]) ? -1.0f : 1.0f) + sigma * z[s];
+      for (int s = 0; 4 * qd + s < n; ++s) {
+        const bool one = src && src[s];
+        const float x = (one ? -1.0f : 1.0f) + sigma * z[s];
+        cherr += (x < 0.0f) != one;
+        dst[s] = x;
+      }
     }
+  }
+  if (counters) {
+    for (int m = 32; m >= 1; m >>= 1) cherr += __shfl_xor(cherr, m, 64);
+    if ((threadIdx.x & 63) == 0 && cherr)
+      atomicAdd(&counters[CC_MC_CHANNEL_BIT_ERRORS], static_cast<unsigned long long>(cherr));
   }
 }
 
@@ -125,7 +142,7 @@ count_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ sent,
     for (int j = lane; j < n; j += 64) {
       const unsigned s = sent ? sent[f * n + j] : 0u;
       biterr += (hard[f * n + j] != s);
-      cherr += ((llr[f * n + j] < 0.0f ? 1u : 0u) != s);
+      if (llr) cherr += ((llr[f * n + j] < 0.0f ? 1u : 0u) != s);  // (null: counted by the channel kernel)
     }
     for (int m = 32; m >= 1; m >>= 1) {
       biterr += __shfl_xor(biterr, m, 64);
@@ -204,7 +221,8 @@ static int ensure_workspace(cc_code *code, size_t chunk) {
 
 // writes y (and the transmitted words when d_sent != nullptr) for frames [first, first + frames)
 int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
-                int random_codewords, float *d_llr, uint8_t *d_sent, uint8_t *d_msg_scratch, hipStream_t stream) {
+                int random_codewords, float *d_llr, uint8_t *d_sent, uint8_t *d_msg_scratch, hipStream_t stream,
+                unsigned long long *d_counters = nullptr) {
   if (frames == 0) return CC_OK;
   const int n = static_cast<int>(code->tab.n), l = static_cast<int>(code->tab.l);
   const float sigma = static_cast<float>(cc_sigma(code, ebno_db));  // normal_distribution<float>(1.0, float(sigma))
@@ -229,7 +247,7 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
   const unsigned long long items = static_cast<unsigned long long>(frames) << group_log2;
   hipLaunchKernelGGL(awgn_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n, group_log2,
                      static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
-                     k1);
+                     k1, d_counters);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "awgn kernel launch");
   return CC_OK;
@@ -248,7 +266,10 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
   const int n = static_cast<int>(code->tab.n);
   for (size_t done = 0; done < frames; done += chunk) {
     const size_t m = frames - done < chunk ? frames - done : chunk;
-    rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, random_codewords, w.llr, w.sent, w.msg, stream);
+    // all-zero transmission (simulation.c++:113-125): no word to keep, nothing to clear or to read back
+    uint8_t *sent = random_codewords ? w.sent : nullptr;
+    rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, random_codewords, w.llr, sent, w.msg, stream,
+                     reinterpret_cast<unsigned long long *>(d_counters));
     if (rc != CC_OK) return rc;
     if (code->soft)
       rc = launch_minsum(code, w.llr, nullptr, nullptr, w.hard, nullptr, w.iters, w.status, m, stream);
@@ -258,7 +279,7 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
     const unsigned long long blocks = (m + 3) / 4;
     const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
     hipLaunchKernelGGL(count_kernel, dim3(static_cast<int>(blocks < max_grid ? blocks : max_grid)), dim3(256), 0, stream,
-                       w.hard, w.sent, w.llr, code->soft ? w.iters : nullptr, w.status, n, code->desc.iterations,
+                       w.hard, sent, nullptr, code->soft ? w.iters : nullptr, w.status, n, code->desc.iterations,
                        static_cast<unsigned long long>(m), reinterpret_cast<unsigned long long *>(d_counters));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "count kernel launch");
