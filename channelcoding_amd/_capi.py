@@ -32,7 +32,7 @@ class Desc(C.Structure):
         ("struct_size", C.c_uint32), ("family", C.c_int32), ("q", C.c_uint32), ("t", C.c_uint32), ("n", C.c_uint32),
         ("mu", C.c_uint32), ("step", C.c_uint32), ("coding", C.c_int32), ("algorithm", C.c_int32),
         ("iterations", C.c_uint32), ("alpha", C.c_double), ("beta", C.c_double), ("stop_rule", C.c_int32),
-        ("device", C.c_int32),
+        ("device", C.c_int32), ("modular_polynomial", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -76,6 +76,14 @@ _SIGNATURES = {
     "cc_mc_run_dev": (C.c_int, [_VP, C.c_double, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, _VP, _VP]),
     "cc_awgn_llr_dev": (C.c_int, [_VP, C.c_double, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, _VP, _VP, _VP]),
     "cc_sigma": (C.c_double, [_VP, C.c_double]),
+    "cc_encode_batch_u16": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "cc_encode_batch_u16_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
+    "cc_correct_hard_batch_u16": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t]),
+    "cc_correct_hard_batch_u16_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "cc_extract_batch_u16": (C.c_int, [_VP, _VP, _VP, C.c_size_t]),
+    "cc_extract_batch_u16_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
+    "cc_get_poly_u16": (C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
+    "cc_q": (C.c_uint32, [_VP]),
     "cc_kernel_info": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                  C.POINTER(C.c_uint32)]),
 }

@@ -160,7 +160,9 @@ class cyclic:
     family = None
 
     def __init__(self, q, capability, algorithm=None, coding="division", mu=1, step=1,
-                 stop_rule=capi.STOP_PARITY, device=None, H=None):
+                 stop_rule=capi.STOP_PARITY, device=None, H=None, modular_polynomial=None):
+        """modular_polynomial: math::modular_polynomial<> (galois.h:23-25), bit i = coefficient of x^i; None = the
+        default of galois.h:18-20, which exists for q <= 8 only.  q > 8: symbols are numpy uint16 / torch int16."""
         if isinstance(capability, int):
             capability = errors(capability)
         algorithm = algorithm if algorithm is not None else peterson_gorenstein_zierler_tag()
@@ -180,6 +182,8 @@ class cyclic:
         d.alpha, d.beta = float(algorithm.alpha), float(algorithm.beta)
         d.stop_rule = int(stop_rule)
         d.device = capi.DEVICE_CURRENT if device is None else int(device)
+        d.modular_polynomial = int(modular_polynomial or 0)
+        self.wide = int(q) > 8
         self._desc = d
         h = C.c_void_p()
         if H is None:
@@ -210,6 +214,12 @@ class cyclic:
         return buf.value.decode()
 
     def _poly(self, which):
+        if self.wide:
+            out = np.zeros(1 << 16, np.uint16)
+            m = capi.lib().cc_get_poly_u16(self._h, which, _ptr(out), out.size)
+            if m < 0:
+                raise CcError(capi.ERR_INVALID_ARGUMENT, "cc_get_poly_u16")
+            return out[:m].copy()
         out = np.zeros(512, np.uint8)
         m = capi.lib().cc_get_poly(self._h, which, _ptr(out), 512)
         if m < 0:
@@ -253,8 +263,65 @@ class cyclic:
         return capi.lib().cc_sigma(self._h, float(ebno_db))
 
     # ---- batch API (numpy host arrays or torch CUDA tensors) ----
+    # ---- q > 8: 16-bit symbols (numpy uint16 on the host, torch int16 / uint16 on the device) ----
+    def _wide_map(self, x, width_in, width_out, host_fn, dev_fn):
+        lib = capi.lib()
+        if _is_torch(x):
+            import torch
+            x = x.contiguous()
+            if x.element_size() != 2 or x.shape[-1] != width_in:
+                raise CcError(capi.ERR_LENGTH, dev_fn)
+            B = x.numel() // width_in
+            out = torch.empty((B, width_out), dtype=x.dtype, device=x.device)
+            capi.check(getattr(lib, dev_fn)(self._h, _ptr(x), _ptr(out), B, _stream_handle(x)), dev_fn)
+            return out
+        x = np.ascontiguousarray(x, np.uint16)
+        if x.shape[-1] != width_in:
+            raise CcError(capi.ERR_LENGTH, host_fn)
+        x = x.reshape(-1, width_in)
+        out = np.zeros((x.shape[0], width_out), np.uint16)
+        capi.check(getattr(lib, host_fn)(self._h, _ptr(x), _ptr(out), x.shape[0]), host_fn)
+        return out
+
+    def _wide_correct(self, b, erasures):
+        lib = capi.lib()
+        if _is_torch(b):
+            import torch
+            b = b.contiguous()
+            if b.element_size() != 2 or b.shape[-1] != self.n:
+                raise CcError(capi.ERR_LENGTH, "correct_batch")
+            B = b.numel() // self.n
+            er = off = None
+            if erasures is not None:
+                ev, eo = _erasure_csr(erasures, B, self.n)
+                if ev is not None:
+                    ev = ev if ev.size else np.zeros(1, ev.dtype)
+                    er = torch.from_numpy(ev.astype(np.int16)).to(b.device)
+                    off = torch.from_numpy(eo.astype(np.int32)).to(b.device)
+            out = torch.empty((B, self.n), dtype=b.dtype, device=b.device)
+            nerr = torch.empty(B, dtype=torch.int32, device=b.device)
+            status = torch.empty(B, dtype=torch.int32, device=b.device)
+            capi.check(lib.cc_correct_hard_batch_u16_dev(self._h, _ptr(b), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
+                                                         _ptr(status), B, _stream_handle(b)),
+                       "cc_correct_hard_batch_u16_dev")
+            return dict(out=out, status=status, nerr=nerr)
+        b = np.ascontiguousarray(b, np.uint16)
+        if b.shape[-1] != self.n:
+            raise CcError(capi.ERR_LENGTH, "correct_batch")
+        b = b.reshape(-1, self.n)
+        B = b.shape[0]
+        er, off = _erasure_csr(erasures, B, self.n)
+        out = np.zeros((B, self.n), np.uint16)
+        nerr = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        capi.check(lib.cc_correct_hard_batch_u16(self._h, _ptr(b), _ptr(er), _ptr(off), _ptr(out), _ptr(nerr),
+                                                 _ptr(status), B), "cc_correct_hard_batch_u16")
+        return dict(out=out, status=status, nerr=nerr)
+
     def encode_batch(self, msg):
         lib = capi.lib()
+        if self.wide:
+            return self._wide_map(msg, self.l, self.n, "cc_encode_batch_u16", "cc_encode_batch_u16_dev")
         if _is_torch(msg):
             import torch
             msg = msg.contiguous()
@@ -275,6 +342,8 @@ class cyclic:
 
     def extract_batch(self, cw):
         lib = capi.lib()
+        if self.wide:
+            return self._wide_map(cw, self.n, self.l, "cc_extract_batch_u16", "cc_extract_batch_u16_dev")
         if _is_torch(cw):
             import torch
             cw = cw.contiguous()
@@ -292,6 +361,8 @@ class cyclic:
         """Returns a dict: out (B,n) u8, status (B,) i32, and nerr (hard) or iters [+ L] (soft)."""
         lib = capi.lib()
         soft_alg = self.algorithm.soft
+        if self.wide:
+            return self._wide_correct(b, erasures)
         if _is_torch(b):
             return self._correct_batch_torch(b, erasures, want_L)
         b = np.asarray(b)
@@ -471,6 +542,7 @@ class min_sum_decoder(cyclic):
         d.alpha, d.beta = float(algorithm.alpha), float(algorithm.beta)
         d.stop_rule = int(stop_rule)
         d.device = capi.DEVICE_CURRENT if device is None else int(device)
+        self.wide = False
         self._desc = d
         h = C.c_void_p()
         capi.check(lib.cc_minsum_create(C.byref(d), _ptr(Hm), Hm.shape[0], Hm.shape[1], C.byref(h)),

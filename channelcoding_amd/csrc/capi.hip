@@ -206,7 +206,27 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
   if (!matrix_only && desc->family != CC_FAMILY_BCH && desc->family != CC_FAMILY_RS) return CC_ERR_INVALID_ARGUMENT;
   if (desc->stop_rule < CC_STOP_AS_SHIPPED || desc->stop_rule > CC_STOP_PARITY) return CC_ERR_INVALID_ARGUMENT;
   if (desc->coding != CC_CODING_DIVISION && desc->coding != CC_CODING_MULTIPLICATION) return CC_ERR_INVALID_ARGUMENT;
-  if (!matrix_only && (desc->q < 2 || desc->q > 8)) return CC_ERR_INVALID_ARGUMENT;
+  if (!matrix_only && (desc->q < 2 || desc->q > 15)) return CC_ERR_INVALID_ARGUMENT;
+  if (desc->reserved != 0) return CC_ERR_INVALID_ARGUMENT;
+  const bool wide = !matrix_only && desc->q > 8;
+  if (wide) {
+    if (is_soft(desc->algorithm) || customH) {
+      set_last_error("min-sum serves matrices of up to 256 columns: q > 8 has hard-decision algorithms only");
+      return CC_ERR_UNSUPPORTED;
+    }
+    if (desc->coding != CC_CODING_DIVISION) {
+      set_last_error("q > 8: division_tag coding only");
+      return CC_ERR_UNSUPPORTED;
+    }
+    if (desc->t > 32) {
+      set_last_error("hard algorithms: one lane per syndrome, t <= 32");
+      return CC_ERR_UNSUPPORTED;
+    }
+    if (desc->family == CC_FAMILY_RS && (desc->mu != 1 || desc->step != 1)) {
+      set_last_error("RS hard decoding with mu / step != 1 is not supported");
+      return CC_ERR_UNSUPPORTED;
+    }
+  }
   if (!matrix_only && desc->n != 0 && desc->n != (1u << desc->q) - 1) {
     set_last_error("shortened codes (N != 2^q-1) are not supported");
     return CC_ERR_UNSUPPORTED;
@@ -233,8 +253,22 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
       code->tab.n = custom_cols;
       code->tab.k = custom_rows;
       code->tab.l = custom_cols > custom_rows ? custom_cols - custom_rows : 0;
+    } else if (wide) {
+      code->wide = true;
+      code->field16.reset(new FieldT<uint16_t>(desc->q, desc->modular_polynomial));
+      code->tab16 = build_code(*code->field16, desc->family, desc->t, desc->mu, desc->step);
+      const CodeTablesT<uint16_t> &w = code->tab16;  // the scalars every getter reads
+      code->tab.family = w.family;
+      code->tab.q = w.q;
+      code->tab.t = w.t;
+      code->tab.n = w.n;
+      code->tab.k = w.k;
+      code->tab.l = w.l;
+      code->tab.dmin = w.dmin;
+      code->tab.mu = w.mu;
+      code->tab.step = w.step;
     } else {
-      code->field.reset(new Field(desc->q));
+      code->field.reset(new Field(desc->q, desc->modular_polynomial));
       code->tab = build_code(*code->field, desc->family, desc->t, desc->mu, desc->step);
     }
   } catch (const std::invalid_argument &e) {
@@ -350,6 +384,31 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     *out = code.release();
     return CC_OK;
   }
+  if (code->wide) {  // tables of the 16-bit path: one allocation {exp, log, g}
+    const FieldT<uint16_t> &f = *code->field16;
+    const CodeTablesT<uint16_t> &w = code->tab16;
+    const size_t ne = f.exp.size(), ng = w.g.size();
+    std::vector<uint16_t> blob(2 * ne + ng + 8, 0);
+    std::copy(f.exp.begin(), f.exp.end(), blob.begin());
+    std::copy(f.log.begin(), f.log.end(), blob.begin() + ne);
+    std::copy(w.g.begin(), w.g.end(), blob.begin() + 2 * ne);
+    CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_wide), blob.size() * sizeof(uint16_t)));
+    CC_HIP_TRY(hipMemcpy(code->d_wide, blob.data(), blob.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    WideTables &wt = code->wide_dev;
+    wt.exp = code->d_wide;
+    wt.log = code->d_wide + ne;
+    wt.g = code->d_wide + 2 * ne;
+    for (size_t i = 0; i < w.root_powers.size() && i < 64; ++i) wt.root_log[i] = w.root_powers[i];
+    wt.n = w.n;
+    wt.k = w.k;
+    wt.l = w.l;
+    wt.t = w.t;
+    wt.nroots = static_cast<uint32_t>(w.roots.size());
+    wt.q = w.q;
+    wt.family = w.family;
+    *out = code.release();
+    return CC_OK;
+  }
   AlgebraicTables &a = code->h_alg;
   std::memset(&a, 0, sizeof a);
   std::memcpy(a.exp, code->field->exp.data(), code->field->exp.size());
@@ -391,6 +450,14 @@ int cc_minsum_create(const cc_desc *desc, const uint8_t *H, uint32_t rows, uint3
   return code_create_impl(desc, H, rows, cols, out);
 }
 
+static int not_wide(const cc_code *code) {
+  if (code->wide) {
+    set_last_error("GF(2^q), q > 8: symbols are 16 bits wide, use the _u16 entry points");
+    return CC_ERR_UNSUPPORTED;
+  }
+  return CC_OK;
+}
+
 static int needs_code(const cc_code *c) {
   if (c->matrix_only) {
     set_last_error("handle was made by cc_minsum_create: it has a parity-check matrix but no code behind it");
@@ -402,6 +469,7 @@ static int needs_code(const cc_code *c) {
 int cc_get_H_alt(const cc_code *c, uint8_t *H, uint32_t *rows) {
   if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
   if (needs_code(c) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(c)) return rc;
   const unsigned n = c->tab.n, q = c->tab.q, t = c->tab.t;
   for (unsigned r = 0; r < t; ++r)
     for (unsigned bit = 0; bit < q; ++bit)
@@ -424,6 +492,7 @@ void cc_code_destroy(cc_code *code) {
     if (code->d_parity) (void)hipFree(code->d_parity);
     if (code->mc) mc_workspace_free(code->mc);
     if (code->stage) host_stage_free(code->stage);
+    if (code->d_wide) (void)hipFree(code->d_wide);
     if (code->d_alg) (void)hipFree(code->d_alg);
   }
   delete code;
@@ -443,15 +512,32 @@ int cc_to_string(const cc_code *c, char *out, size_t cap) {
 }
 
 int cc_get_poly(const cc_code *c, int which, uint8_t *out, size_t cap) {
-  if (!c || !out) return -1;
+  if (!c || !out || c->wide) return -1;
   const std::vector<uint8_t> *v = which == 0 ? &c->tab.g : which == 1 ? &c->tab.h : which == 2 ? &c->tab.roots : nullptr;
   if (!v || v->size() > cap) return -1;
   std::memcpy(out, v->data(), v->size());
   return static_cast<int>(v->size());
 }
 
+int cc_get_poly_u16(const cc_code *c, int which, uint16_t *out, size_t cap) {
+  if (!c || !out || which < 0 || which > 2) return -1;
+  if (c->wide) {
+    const std::vector<uint16_t> &v = which == 0 ? c->tab16.g : which == 1 ? c->tab16.h : c->tab16.roots;
+    if (v.size() > cap) return -1;
+    std::copy(v.begin(), v.end(), out);
+    return static_cast<int>(v.size());
+  }
+  const std::vector<uint8_t> &v = which == 0 ? c->tab.g : which == 1 ? c->tab.h : c->tab.roots;
+  if (v.size() > cap) return -1;
+  std::copy(v.begin(), v.end(), out);
+  return static_cast<int>(v.size());
+}
+
+uint32_t cc_q(const cc_code *c) { return c ? c->tab.q : 0; }
+
 int cc_get_H(const cc_code *c, uint8_t *H) {
   if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
+  if (c->wide) return CC_ERR_UNSUPPORTED;
   const unsigned n = c->tab.n;
   if (c->matrix_only) {
     std::memcpy(H, c->custom_H.data(), c->custom_H.size());
@@ -539,6 +625,7 @@ int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t 
 /* ------------------------------ hard decode ------------------------------ */
 
 static int hard_supported(const cc_code *code, bool erasures) {
+  if (int rc = not_wide(code)) return rc;
   if (code->soft) {
     set_last_error("code was created with a min-sum algorithm; use cc_correct_soft_batch");
     return CC_ERR_INVALID_ARGUMENT;
@@ -685,6 +772,7 @@ int cc_correct_hard_f32_batch(const cc_code *code, const float *in, const uint16
 int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, void *stream) {
   if (!code || (B && (!d_msg || !d_cw))) return CC_ERR_INVALID_ARGUMENT;
   if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(code)) return rc;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   DeviceGuard guard(code->device);
   return launch_encode(code, d_msg, d_cw, B, static_cast<hipStream_t>(stream));
@@ -693,6 +781,7 @@ int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw
 int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_msg, size_t B, void *stream) {
   if (!code || (B && (!d_cw || !d_msg))) return CC_ERR_INVALID_ARGUMENT;
   if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(code)) return rc;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   DeviceGuard guard(code->device);
   return launch_extract(code, d_cw, d_msg, B, static_cast<hipStream_t>(stream));
@@ -701,6 +790,7 @@ int cc_extract_batch_dev(const cc_code *code, const uint8_t *d_cw, uint8_t *d_ms
 static int byte_map_host(const cc_code *code, bool encode, const uint8_t *src, uint8_t *dst, size_t B) {
   if (!code || (B && (!src || !dst))) return CC_ERR_INVALID_ARGUMENT;
   if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(code)) return rc;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   if (B == 0) return CC_OK;
   const size_t n = code->tab.n, l = code->tab.l;
@@ -746,6 +836,7 @@ static int decode_host(const cc_code *code, bool float_in, const void *in, const
                        int32_t *status, size_t B) {
   if (!code || (B && (!in || !msg))) return CC_ERR_INVALID_ARGUMENT;
   if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(code)) return rc;
   if (B == 0) return CC_OK;
   std::vector<uint8_t> tmp;
   if (!words) {
@@ -780,10 +871,138 @@ int cc_decode_soft_batch(const cc_code *code, const float *y, const uint16_t *er
   return decode_host(code, true, y, erasures, erasure_offsets, msg, words, iters, nullptr, status, B);
 }
 
+/* ------------------------------ q = 9 .. 15: 16-bit symbols (wide.hip) ------------------------------ */
+
+static int wide_ready(const cc_code *code) {
+  if (!code->wide) {
+    set_last_error("the _u16 entry points serve GF(2^q) with q > 8; this handle has byte symbols");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
+  return CC_OK;
+}
+
+int cc_encode_batch_u16_dev(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, void *stream) {
+  if (!code || (B && (!d_msg || !d_cw))) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = wide_ready(code)) return rc;
+  DeviceGuard guard(code->device);
+  return launch_wide_encode(code, d_msg, d_cw, B, static_cast<hipStream_t>(stream));
+}
+
+int cc_extract_batch_u16_dev(const cc_code *code, const uint16_t *d_cw, uint16_t *d_msg, size_t B, void *stream) {
+  if (!code || (B && (!d_cw || !d_msg))) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = wide_ready(code)) return rc;
+  DeviceGuard guard(code->device);
+  return launch_wide_extract(code, d_cw, d_msg, B, static_cast<hipStream_t>(stream));
+}
+
+int cc_correct_hard_batch_u16_dev(const cc_code *code, const uint16_t *d_in, const uint16_t *d_erasures,
+                                  const uint32_t *d_erasure_offsets, uint16_t *d_out, int32_t *d_nerr,
+                                  int32_t *d_status, size_t B, void *stream) {
+  if (!code || (B && (!d_in || !d_out))) return CC_ERR_INVALID_ARGUMENT;
+  if ((d_erasures == nullptr) != (d_erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = wide_ready(code)) return rc;
+  if (d_erasures && code->desc.algorithm == CC_ALG_PGZ) {
+    set_last_error("PGZ with erasures on 16-bit symbols is not supported");  // (RS: the reference throws, hard_decision.h:66-68)
+    return CC_ERR_UNSUPPORTED;
+  }
+  DeviceGuard guard(code->device);
+  return launch_wide_correct(code, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
+                             static_cast<hipStream_t>(stream));
+}
+
+// host pointers: same chunked staging as the byte entry points; kind 0 = encode, 1 = extract
+static int wide_map_host(const cc_code *code, int kind, const uint16_t *src, uint16_t *dst, size_t B) {
+  if (!code || (B && (!src || !dst))) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = wide_ready(code)) return rc;
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n, l = code->tab.l;
+  const size_t in_w = kind == 0 ? l : n, out_w = kind == 0 ? n : l;
+  if (kind == 0)
+    for (size_t i = 0; i < B * in_w; ++i)
+      if (src[i] > n) return CC_ERR_NOT_IN_FIELD;  // Element(e) throws, galois.h:149-152
+  DeviceGuard guard(code->device);
+  StageLock sl(code);
+  if (sl.rc != CC_OK) return sl.rc;
+  HostStage &st = *sl.st;
+  const size_t CH = chunk_frames(n * 2, B);
+  size_t k = 0;
+  for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
+    const int slot = static_cast<int>(k & 1);
+    const size_t m = B - c0 < CH ? B - c0 : CH;
+    hipStream_t s = st.stream[slot];
+    CC_HIP_TRY(hipStreamSynchronize(s));
+    uint16_t *d_src = nullptr, *d_dst = nullptr;
+    if (int r = st.get(slot, 0, m * in_w, &d_src)) return r;
+    if (int r = st.get(slot, 1, m * out_w, &d_dst)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(d_src, src + c0 * in_w, m * in_w * 2, hipMemcpyHostToDevice, s));
+    const int rc = kind == 0 ? launch_wide_encode(code, d_src, d_dst, m, s) : launch_wide_extract(code, d_src, d_dst, m, s);
+    if (rc != CC_OK) return rc;
+    CC_HIP_TRY(hipMemcpyAsync(dst + c0 * out_w, d_dst, m * out_w * 2, hipMemcpyDeviceToHost, s));
+  }
+  return st.drain();
+}
+
+int cc_encode_batch_u16(const cc_code *code, const uint16_t *msg, uint16_t *cw, size_t B) {
+  return wide_map_host(code, 0, msg, cw, B);
+}
+int cc_extract_batch_u16(const cc_code *code, const uint16_t *cw, uint16_t *msg, size_t B) {
+  return wide_map_host(code, 1, cw, msg, B);
+}
+
+int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in, const uint16_t *erasures,
+                              const uint32_t *erasure_offsets, uint16_t *out, int32_t *nerr, int32_t *status,
+                              size_t B) {
+  if (!code || (B && (!in || !out))) return CC_ERR_INVALID_ARGUMENT;
+  if ((erasures == nullptr) != (erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = wide_ready(code)) return rc;
+  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
+    set_last_error("PGZ with erasures on 16-bit symbols is not supported");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n;
+  for (size_t i = 0; i < B * n; ++i)
+    if (in[i] > n) return CC_ERR_NOT_IN_FIELD;
+  if (erasures) {
+    const size_t ne = erasure_offsets[B];
+    for (size_t e = 0; e < ne; ++e)
+      if (erasures[e] >= n) return CC_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard guard(code->device);
+  StageLock sl(code);
+  if (sl.rc != CC_OK) return sl.rc;
+  HostStage &st = *sl.st;
+  const size_t CH = chunk_frames(n * 2, B);
+  size_t k = 0;
+  for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
+    const int slot = static_cast<int>(k & 1);
+    const size_t m = B - c0 < CH ? B - c0 : CH;
+    hipStream_t s = st.stream[slot];
+    CC_HIP_TRY(hipStreamSynchronize(s));
+    uint16_t *d_in = nullptr, *d_out = nullptr;
+    int32_t *d_nerr = nullptr, *d_status = nullptr;
+    const uint16_t *d_er = nullptr;
+    const uint32_t *d_off = nullptr;
+    if (int r = st.get(slot, 0, m * n, &d_in)) return r;
+    if (int r = st.get(slot, 1, m * n, &d_out)) return r;
+    if (int r = st.get(slot, 2, m, &d_nerr)) return r;
+    if (int r = st.get(slot, 3, m, &d_status)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(d_in, in + c0 * n, m * n * 2, hipMemcpyHostToDevice, s));
+    if (int r = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return r;
+    if (int r = launch_wide_correct(code, d_in, d_er, d_off, d_out, d_nerr, d_status, m, s)) return r;
+    CC_HIP_TRY(hipMemcpyAsync(out + c0 * n, d_out, m * n * 2, hipMemcpyDeviceToHost, s));
+    if (nerr) CC_HIP_TRY(hipMemcpyAsync(nerr + c0, d_nerr, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+  return st.drain();
+}
+
 /* ------------------------------ Monte-Carlo ------------------------------ */
 
 static int mc_supported(const cc_code *code) {
   if (needs_code(code) != CC_OK) return CC_ERR_INVALID_ARGUMENT;
+  if (int rc = not_wide(code)) return rc;
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
   if (code->tab.family != CC_FAMILY_BCH) {
     set_last_error("the BPSK/AWGN Monte-Carlo channel is defined for binary (BCH) codes");

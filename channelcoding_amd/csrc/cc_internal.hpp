@@ -45,6 +45,15 @@ struct AlgebraicTables {
   int n, k, l, t, nroots, family, q;
 };
 
+// q = 9..15 (wide.hip): tables in global memory, passed to the kernels by value
+struct WideTables {
+  const uint16_t *exp = nullptr, *log = nullptr;  // 2 * 2^q entries each
+  const uint16_t *g = nullptr;                    // k + 1 coefficients
+  uint32_t root_log[64] = {0};
+  uint32_t n = 0, k = 0, l = 0, t = 0, nroots = 0, q = 0;
+  int family = 0;
+};
+
 }  // namespace ccamd
 
 namespace ccamd {
@@ -59,6 +68,12 @@ struct cc_code {
   int device = 0;
   std::unique_ptr<ccamd::Field> field;
   ccamd::CodeTables tab;
+  // q = 9..15: symbols are uint16_t; `tab` then only carries the scalars (n, k, l, t, dmin, ...)
+  bool wide = false;
+  std::unique_ptr<ccamd::FieldT<uint16_t>> field16;
+  ccamd::CodeTablesT<uint16_t> tab16;
+  ccamd::WideTables wide_dev;
+  uint16_t *d_wide = nullptr;  // one allocation behind wide_dev's pointers
   bool soft = false;
   std::vector<uint8_t> custom_H;  // rows x n, empty = the code's own H()
   bool matrix_only = false;  // cc_minsum_create: no field / code tables
@@ -125,6 +140,11 @@ int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in,
                            int32_t *d_status, size_t B, hipStream_t stream);
 int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,
                         uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
+// wide.hip
+int launch_wide_correct(const cc_code *code, const uint16_t *d_in, const uint16_t *d_er, const uint32_t *d_off,
+                        uint16_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
+int launch_wide_encode(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, hipStream_t stream);
+int launch_wide_extract(const cc_code *code, const uint16_t *d_cw, uint16_t *d_msg, size_t B, hipStream_t stream);
 // encode.hip
 std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t);
 int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);

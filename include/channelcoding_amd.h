@@ -81,7 +81,7 @@ typedef enum cc_stop_rule {
 typedef struct cc_desc {
   uint32_t struct_size; /* = sizeof(cc_desc)                                                   */
   int32_t family;       /* cc_family                                                           */
-  uint32_t q;           /* GF(2^q), 3..8; default modular polynomials of galois.h:18-20        */
+  uint32_t q;           /* GF(2^q), 2..15; q > 8: name modular_polynomial below, use the _u16 calls */
   uint32_t t;           /* errors<t>; for dmin<d> pass (d-1)/2 (codes.h:14-26)                 */
   uint32_t n;           /* 0 or 2^q-1 (the reference's N is a TODO there too, cyclic.h:66)     */
   uint32_t mu, step;    /* RS only: roots alpha^(mu + i*step), rs.h:18-39; use 1, 1            */
@@ -92,6 +92,10 @@ typedef struct cc_desc {
   double beta;          /* OMS: ::beta (used in double); 2D-NMS: ::beta = Beta::num/Alpha::den */
   int32_t stop_rule;    /* cc_stop_rule                                                        */
   int32_t device;       /* HIP device ordinal, CC_DEVICE_CURRENT, or CC_DEVICE_NONE            */
+  uint32_t modular_polynomial; /* math::modular_polynomial<> (galois.h:23-25): bit i = coefficient of x^i, degree q,
+                                * primitive.  0 = the default of galois.h:18-20, which exists for q <= 8 only
+                                * (default_modular_polynomial, galois.h:57-67) */
+  uint32_t reserved;    /* 0 */
 } cc_desc;
 
 #define CC_DEVICE_CURRENT (-1)
@@ -219,6 +223,24 @@ int cc_mc_run_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t f
 int cc_awgn_llr_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
                     int random_codewords, float *d_llr, uint8_t *d_sent, void *stream);
 double cc_sigma(const cc_code *code, double ebno_db); /* simulation.c++:83-85 */
+
+/* ---- fields GF(2^q) with q = 9 .. 15 (galois.h:44-53: "uint16_t allows galois fields up to 2^15"): symbols are
+ *      16 bits wide, n = 2^q - 1 <= 32767.  Hard-decision algorithms (PGZ as bounded-distance BM, BM, Euklid), with
+ *      erasures; division_tag coding.  The byte entry points above return CC_ERR_UNSUPPORTED on such a handle and
+ *      these return it on a q <= 8 handle.  Min-sum (n <= 256 only) and the Monte-Carlo calls do not apply. ---- */
+int cc_encode_batch_u16(const cc_code *code, const uint16_t *msg /* B*l */, uint16_t *cw /* B*n */, size_t B);
+int cc_encode_batch_u16_dev(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, void *stream);
+int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in /* B*n symbols */, const uint16_t *erasures,
+                              const uint32_t *erasure_offsets, uint16_t *out /* B*n */, int32_t *nerr, int32_t *status,
+                              size_t B);
+int cc_correct_hard_batch_u16_dev(const cc_code *code, const uint16_t *d_in, const uint16_t *d_erasures,
+                                  const uint32_t *d_erasure_offsets, uint16_t *d_out, int32_t *d_nerr,
+                                  int32_t *d_status, size_t B, void *stream);
+int cc_extract_batch_u16(const cc_code *code, const uint16_t *cw /* B*n */, uint16_t *msg /* B*l */, size_t B);
+int cc_extract_batch_u16_dev(const cc_code *code, const uint16_t *d_cw, uint16_t *d_msg, size_t B, void *stream);
+/* cc_get_poly for 16-bit coefficients (works on every handle) */
+int cc_get_poly_u16(const cc_code *code, int which, uint16_t *out, size_t cap);
+uint32_t cc_q(const cc_code *code);
 
 /* ---- introspection for the benchmark: name and launch geometry of the kernel a call would use ---- */
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,

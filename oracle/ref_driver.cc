@@ -71,6 +71,20 @@ auto matrix<math::ef_element<2, 1>>::end() const noexcept -> const_iterator {
 }
 #endif
 
+// q > 8: the reference carries default modular polynomials for q <= 8 only and asks for the rest to be "specified
+// manually" (src/math/galois.h:57-67).  These explicit specialisations ARE that manual specification -- user code in
+// the sense of the reference, no source of it is touched; they must precede the first use in cyclic.h.
+namespace math {
+namespace detail {
+template <> struct default_modular_polynomial<9> {
+  using type = ::math::modular_polynomial<0x211>;  // x^9 + x^4 + 1
+};
+template <> struct default_modular_polynomial<10> {
+  using type = ::math::modular_polynomial<0x409>;  // x^10 + x^3 + 1
+};
+}  // namespace detail
+}  // namespace math
+
 #include "codes/bch.h"
 #include "codes/rs.h"
 
@@ -753,4 +767,131 @@ API int ref_tag_constants(double *nms_8_10_alpha, double *oms_1_100_beta, double
   *d2_34_910_alpha = normalized_2d_min_sum_tag<10, std::ratio<3, 4>, std::ratio<9, 10>>::alpha;
   *d2_34_910_beta = normalized_2d_min_sum_tag<10, std::ratio<3, 4>, std::ratio<9, 10>>::beta;
   return ST_OK;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * q > 8: symbols are uint16_t (the reference's storage_type, galois.h:44-53).  Two codes, three / two algorithms:
+ *   wide id 0: primitive_bch<9, errors<3>>   (511, 484, 7)     PGZ, BM, Euklid
+ *   wide id 1: rs<10, errors<4>>             (1023, 1015, 10)  PGZ, BM, Euklid
+ * ------------------------------------------------------------------------------------------------------------- */
+namespace {
+struct wide_iface {
+  virtual ~wide_iface() = default;
+  unsigned n = 0, k = 0, l = 0, t = 0, dmin = 0, q = 0;
+  int family = 0;
+  std::vector<uint16_t> g, h, roots;
+  virtual std::string to_string(int alg) const = 0;
+  virtual void encode(const uint16_t *msg, uint16_t *cw) const = 0;
+  virtual void correct(int alg, const uint16_t *in, const std::vector<unsigned> &er, uint16_t *out) const = 0;
+  virtual void decode(int alg, const uint16_t *in, const std::vector<unsigned> &er, uint16_t *out) const = 0;
+};
+template <typename PGZ, typename BM, typename EUK> struct wide_impl : wide_iface {
+  Peek<PGZ> pgz;
+  Peek<BM> bm;
+  Peek<EUK> euk;
+  wide_impl(int family_, unsigned q_) {
+    family = family_;
+    q = q_;
+    n = PGZ::n;
+    t = PGZ::t;
+    k = pgz.K();
+    l = pgz.Lm();
+    dmin = pgz.D();
+    for (const auto &e : pgz.G()) g.push_back(static_cast<uint16_t>(static_cast<unsigned>(e)));
+    for (const auto &e : pgz.Hp()) h.push_back(static_cast<uint16_t>(static_cast<unsigned>(e)));
+    for (const auto &e : pgz.R()) roots.push_back(static_cast<uint16_t>(static_cast<unsigned>(e)));
+  }
+  std::string to_string(int alg) const override {
+    return alg == ALG_PGZ ? pgz.to_string() : alg == ALG_BM ? bm.to_string() : euk.to_string();
+  }
+  void encode(const uint16_t *msg, uint16_t *cw) const override {
+    std::vector<uint16_t> a(msg, msg + l), out;
+    pgz.encode(a, std::back_inserter(out));
+    if (out.size() != n) throw std::logic_error("encode produced wrong length");
+    std::copy(out.begin(), out.end(), cw);
+  }
+  void correct(int alg, const uint16_t *in, const std::vector<unsigned> &er, uint16_t *out) const override {
+    std::vector<uint16_t> b(in, in + n), r;
+    switch (alg) {
+    case ALG_PGZ: r = pgz.template correct<uint16_t>(b, er); break;
+    case ALG_BM: r = bm.template correct<uint16_t>(b, er); break;
+    default: r = euk.template correct<uint16_t>(b, er); break;
+    }
+    if (r.size() != n) throw std::logic_error("correct produced wrong length");
+    std::copy(r.begin(), r.end(), out);
+  }
+  void decode(int alg, const uint16_t *in, const std::vector<unsigned> &er, uint16_t *out) const override {
+    std::vector<uint16_t> b(in, in + n), r;
+    switch (alg) {
+    case ALG_PGZ: r = pgz.template decode<std::vector<uint16_t>, uint16_t>(b, er); break;
+    case ALG_BM: r = bm.template decode<std::vector<uint16_t>, uint16_t>(b, er); break;
+    default: r = euk.template decode<std::vector<uint16_t>, uint16_t>(b, er); break;
+    }
+    if (r.size() != l) throw std::logic_error("decode produced wrong length");
+    std::copy(r.begin(), r.end(), out);
+  }
+};
+std::vector<std::unique_ptr<wide_iface>> &wide_codes() {
+  static std::vector<std::unique_ptr<wide_iface>> v = [] {
+    std::vector<std::unique_ptr<wide_iface>> c;
+    c.emplace_back(new wide_impl<cyclic::primitive_bch<9, errors<3>, cyclic::peterson_gorenstein_zierler_tag>,
+                                 cyclic::primitive_bch<9, errors<3>, cyclic::berlekamp_massey_tag>,
+                                 cyclic::primitive_bch<9, errors<3>, cyclic::euklid_tag>>(0, 9));
+    c.emplace_back(new wide_impl<cyclic::rs<10, errors<4>, cyclic::peterson_gorenstein_zierler_tag>,
+                                 cyclic::rs<10, errors<4>, cyclic::berlekamp_massey_tag>,
+                                 cyclic::rs<10, errors<4>, cyclic::euklid_tag>>(1, 10));
+    return c;
+  }();
+  return v;
+}
+wide_iface *wget(int id) {
+  auto &v = wide_codes();
+  return (id >= 0 && static_cast<size_t>(id) < v.size()) ? v[static_cast<size_t>(id)].get() : nullptr;
+}
+}  // namespace
+
+API int refw_num_codes(void) { return static_cast<int>(wide_codes().size()); }
+API int refw_info(int id, int *family, unsigned *q, unsigned *n, unsigned *k, unsigned *l, unsigned *t, unsigned *dmin) {
+  auto c = wget(id);
+  if (!c) return ST_BAD_ARG;
+  *family = c->family;
+  *q = c->q;
+  *n = c->n;
+  *k = c->k;
+  *l = c->l;
+  *t = c->t;
+  *dmin = c->dmin;
+  return ST_OK;
+}
+API int refw_get_poly(int id, int which, uint16_t *out, int cap) {
+  auto c = wget(id);
+  if (!c) return -1;
+  const std::vector<uint16_t> &v = which == 0 ? c->g : which == 1 ? c->h : c->roots;
+  if (static_cast<int>(v.size()) > cap) return -1;
+  std::copy(v.begin(), v.end(), out);
+  return static_cast<int>(v.size());
+}
+API int refw_to_string(int id, int alg, char *out, int cap) {
+  auto c = wget(id);
+  if (!c) return ST_BAD_ARG;
+  set_what(out, cap, c->to_string(alg).c_str());
+  return ST_OK;
+}
+API int refw_encode(int id, const uint16_t *msg, uint16_t *cw, char *what, int whatlen) {
+  auto c = wget(id);
+  if (!c) return ST_BAD_ARG;
+  return guarded(what, whatlen, [&] { c->encode(msg, cw); });
+}
+API int refw_correct(int id, int alg, const uint16_t *in, const unsigned *er, int ne, uint16_t *out, char *what,
+                     int whatlen) {
+  auto c = wget(id);
+  if (!c) return ST_BAD_ARG;
+  return guarded(what, whatlen, [&] { c->correct(alg, in, er_vec(er, ne), out); });
+}
+API int refw_decode(int id, int alg, const uint16_t *in, const unsigned *er, int ne, uint16_t *out, char *what,
+                    int whatlen) {
+  auto c = wget(id);
+  if (!c) return ST_BAD_ARG;
+  return guarded(what, whatlen, [&] { c->decode(alg, in, er_vec(er, ne), out); });
 }

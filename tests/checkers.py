@@ -378,3 +378,54 @@ def awgn_llr(rng, codewords, rate, ebno_db):
     c = np.asarray(codewords, np.float32)
     noise = rng.standard_normal(c.shape).astype(np.float32)
     return ((1.0 - 2.0 * c) + np.float32(sigma) * noise).astype(np.float32)
+
+
+class RefWide:
+    """The real reference on GF(2^q), q > 8 (oracle/ref_driver.cc, "wide" section): uint16 symbols.
+    wide id 0 = primitive_bch<9, errors<3>> with modular polynomial 0x211, id 1 = rs<10, errors<4>> with 0x409."""
+    CODES = {0: (BCH, 9, 3, 0x211), 1: (RS, 10, 4, 0x409)}
+
+    @staticmethod
+    def available():
+        return RefLib.available() and hasattr(RefLib.get(1).lib, "refw_num_codes")
+
+    def __init__(self, wid):
+        self.lib = RefLib.get(1).lib
+        self.wid = wid
+        v = [C.c_int()] + [C.c_uint() for _ in range(6)]
+        assert self.lib.refw_info(wid, *[C.byref(x) for x in v]) == 0
+        self.family, self.q, self.n, self.k, self.l, self.t, self.dmin = [x.value for x in v]
+
+    def poly(self, which):
+        out = np.zeros(1 << 16, np.uint16)
+        m = self.lib.refw_get_poly(self.wid, which, _ptr(out), out.size)
+        assert m >= 0
+        return out[:m].copy()
+
+    def to_string(self, alg):
+        buf = C.create_string_buffer(128)
+        self.lib.refw_to_string(self.wid, alg, buf, 128)
+        return buf.value.decode()
+
+    def encode(self, msg):
+        msg = np.ascontiguousarray(msg, np.uint16).reshape(-1, self.l)
+        cw = np.zeros((msg.shape[0], self.n), np.uint16)
+        w = C.create_string_buffer(256)
+        for f in range(msg.shape[0]):
+            assert self.lib.refw_encode(self.wid, _ptr(msg[f]), _ptr(cw[f]), w, 256) == 0, w.value
+        return cw
+
+    def correct(self, alg, frames, erasures=None, decode=False):
+        """Returns out (B, n or l) u16, status (B,) (0 ok, 1 decoding_failure, 2 runtime_error), messages."""
+        frames = np.ascontiguousarray(frames, np.uint16).reshape(-1, self.n)
+        B = frames.shape[0]
+        out = np.zeros((B, self.l if decode else self.n), np.uint16)
+        status = np.zeros(B, np.int32)
+        msgs = []
+        w = C.create_string_buffer(512)
+        fn = self.lib.refw_decode if decode else self.lib.refw_correct
+        for f in range(B):
+            er = np.asarray(erasures[f] if erasures is not None else (), np.uint32)
+            status[f] = fn(self.wid, alg, _ptr(frames[f]), _ptr(er) if len(er) else None, len(er), _ptr(out[f]), w, 512)
+            msgs.append(w.value.decode(errors="replace"))
+        return out, status, msgs

@@ -160,3 +160,33 @@ def test_benchmark_cli_selection():
     with pytest.raises(SystemExit):
         benchmark.select(None, ["8"], None)
     assert benchmark.main(["--simulation", "fading"]) == 1 and benchmark.main(["--bogus"]) == 1
+
+
+def test_wide_field_code_constants_match_reference_vectors():
+    """GF(2^q), q > 8 (galois.h:23-25,44-53,57-75): g, h, roots, (n, k, l, dmin) and to_string of the codes in
+    tests/golden/wide.npz (vectors of the real reference) from the host-side construction, no GPU needed."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide.npz"))
+    tags = (cc.peterson_gorenstein_zierler_tag, cc.berlekamp_massey_tag, cc.euklid_tag)
+    for wid in (0, 1):
+        p = "w%d_" % wid
+        fam, q, t, poly, n, k, l, dmin = [int(v) for v in gold[p + "params"]]
+        mk = cc.primitive_bch if fam == 0 else cc.rs
+        codes = [mk(q, cc.errors(t), tag(), device=capi.DEVICE_NONE, modular_polynomial=poly) for tag in tags]
+        code = codes[0]
+        assert code.wide and (code.n, code.k, code.l, code.dmin) == (n, k, l, dmin)
+        assert [c.to_string() for c in codes] == list(gold[p + "names"])
+        assert np.array_equal(code.g, gold[p + "g"]) and np.array_equal(code.h, gold[p + "h"])
+        assert np.array_equal(code.roots, gold[p + "roots"])
+        with pytest.raises(cc.CcError) as e:  # no CPU decode path for wide symbols either
+            code.encode_batch(np.zeros((1, l), np.uint16))
+        assert e.value.status == capi.ERR_NO_DEVICE
+    # the reference has no default polynomial beyond q = 8 (galois.h:57-67): the caller must name one
+    with pytest.raises(cc.CcError):
+        cc.primitive_bch(9, cc.errors(3), cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE)
+    with pytest.raises(cc.CcError):
+        cc.primitive_bch(9, cc.errors(3), cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE, modular_polynomial=0x201)
+    # every q up to 15 (uint16_t storage, galois.h:44-53) constructs; n = 2^q - 1
+    for q, poly in ((9, 0x211), (10, 0x409), (11, 0x805), (12, 0x1053), (13, 0x201B), (14, 0x4443), (15, 0x8003)):
+        c = cc.rs(q, cc.errors(2), cc.euklid_tag(), device=capi.DEVICE_NONE, modular_polynomial=poly)
+        assert c.n == (1 << q) - 1 and c.k == 4 and c.to_string() == "(%d, %d, 6)-EUKLID" % (c.n, c.n - 4)

@@ -332,3 +332,24 @@ def test_multiplication_tag_coding(ref_libs, cid):
     rx = rng.integers(0, hi, (40, o.n)).astype(np.uint8)
     rx[0, -5:] = 0
     assert np.array_equal(o.extract(np.concatenate([cw, rx])), ref0.decode_mult(cid, np.concatenate([cw, rx])))
+
+
+def test_wide_reference_build_matches_its_golden_vectors(ref_libs):
+    """oracle/_ref carries two codes over GF(2^9) / GF(2^10) (ref_driver.cc, "wide" section: the modular
+    polynomials are named through default_modular_polynomial<> specialisations, as galois.h:57-67 asks).
+    tests/golden/wide.npz must be what that build produces today."""
+    import os
+    from checkers import RefWide
+    if not RefWide.available():
+        pytest.skip("oracle/_ref predates the wide section")
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide.npz"))
+    for wid in RefWide.CODES:
+        r = RefWide(wid)
+        p = "w%d_" % wid
+        assert [r.n, r.k, r.l, r.dmin] == [int(v) for v in gold[p + "params"][4:]]
+        assert np.array_equal(r.poly(0), gold[p + "g"]) and np.array_equal(r.poly(2), gold[p + "roots"])
+        assert np.array_equal(r.encode(gold[p + "msg"][:6]), gold[p + "cw"][:6])
+        for alg, name in ((PGZ, "pgz"), (BM, "bm"), (EUKLID, "euklid")):
+            out, st, _ = r.correct(alg, gold[p + "rx"][:10])
+            assert np.array_equal(st, gold[p + name + "_status"][:10])
+            assert np.array_equal(out[st == 0], gold[p + name + "_out"][:10][st == 0])
