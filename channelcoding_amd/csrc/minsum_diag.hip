@@ -9,7 +9,7 @@
 namespace ccamd {
 
 // Geometries with a diagonal instantiation: minsum_diag_geos.inc, one object file each.
-#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA)                                                                 \
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK)                                                             \
   int launch_minsum_diag_##NAME(const cc_code *, const MinSumParams &, const float *, const uint16_t *,              \
                                 const uint32_t *, uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
 #include "minsum_diag_geos.inc"
@@ -22,7 +22,7 @@ struct DiagEntry {
   DiagLaunch launch;
 };
 const DiagEntry kDiagGeometries[] = {
-#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA) {{N, KK, W, DD, LL, CC, SC}, &launch_minsum_diag_##NAME},
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK) {{N, KK, W, DD, LL, CC, SC, LK, {1, 1, 1, 1}}, &launch_minsum_diag_##NAME},
 #include "minsum_diag_geos.inc"
 #undef GEO
 };

@@ -7,6 +7,9 @@
     !defined(GEO_OCC) || !defined(GEO_SCMS) || !defined(GEO_PARTIAL)
 #error "compile through the Makefile: one geometry of minsum_diag_geos.inc per object"
 #endif
+#ifndef GEO_LINKS
+#define GEO_LINKS 0
+#endif
 #define CC_GEO_CAT2(a, b) a##b
 #define CC_GEO_CAT(a, b) CC_GEO_CAT2(a, b)
 
@@ -16,8 +19,16 @@ int CC_GEO_CAT(launch_minsum_diag_, GEO_NAME)(const cc_code *code, const MinSumP
                                               const uint16_t *d_er, const uint32_t *d_er_off, uint8_t *d_hard,
                                               float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B,
                                               hipStream_t stream) {
+#if GEO_LINKS == 2
+  return launch_diag_geometry<GEO_K, GEO_D, GEO_LPF, GEO_CPL, GEO_OCC, GEO_SCMS, GEO_PARTIAL, PairGaps<1, 1>, true>(
+      code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
+#elif GEO_LINKS == 1
+  return launch_diag_geometry<GEO_K, GEO_D, GEO_LPF, GEO_CPL, GEO_OCC, GEO_SCMS, GEO_PARTIAL, PairGaps<1>, true>(
+      code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
+#else
   return launch_diag_geometry<GEO_K, GEO_D, GEO_LPF, GEO_CPL, GEO_OCC, GEO_SCMS, GEO_PARTIAL>(
       code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
+#endif
 }
 
 }  // namespace ccamd

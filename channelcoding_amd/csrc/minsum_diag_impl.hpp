@@ -193,8 +193,13 @@ __device__ __forceinline__ float horizontal(float m, float alpha_f, double beta_
 // SINGLE: every frame runs exactly one iteration (stop rule O0 "as shipped", or Iterations == 1): all messages
 // and column sums are zero when that iteration starts, so q = (0 - 0) + y = y (y is never -0.0f) -- no {cs, r}
 // operands, no subtraction / addition, and no message registers at all.
+// CHAIN: the PG pairs are gap-1 links -- slots 2p (the "tail", diagonal s) and 2p + 1 (the "head", diagonal s + 1)
+// of a lane.  The head's edge of row i and the tail's edge of row i + 1 sit in the SAME column s + 1 + i, and no
+// other diagonal touches that column in between, so the tail takes the {cs, y} pair the head read one row earlier
+// and continues the head's running column sum in registers: per link and row one {cs, y} read, one cs' read and
+// one cs' write less, in the reference's summation order (soft_decision.h:88-95) all the same.
 template <int K, int D, int VARIANT, int RB, int LPF, int CPL, int OCC, bool PARTIAL, typename PG = PairGaps<>,
-          bool SINGLE = false>
+          bool SINGLE = false, bool CHAIN = false>
 __global__ void __launch_bounds__(256, OCC)
 minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const uint32_t *__restrict__ colbits,
                    const float *__restrict__ llr, const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
@@ -203,6 +208,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   static_assert(K % RB == 0 && K <= 32, "row batching");
   static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
   static_assert(2 * PG::NP <= D && !(PARTIAL && PG::NP > 0), "paired slots");
+  static_assert(!CHAIN || PG::NP == 0 || (PG::gap(0) == 1 && PG::gap(PG::NP - 1) == 1), "links are gap-1 pairs");
+  constexpr int NLK = CHAIN ? PG::NP : 0;  // links; slot 2p = tail, 2p + 1 = head for p < NLK
   constexpr int FPW = 64 / LPF;          // frames per wavefront
   // columns of one frame's LDS region: + 16 pad (odd frames start 16 banks later); PARTIAL geometries (row weight
   // not a multiple of LPF) append 32 scratch columns that absorb the accesses of the lanes whose last slot is empty
@@ -367,13 +374,20 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     //  the bit words below take the 14 registers the prefetch would hold)
     constexpr bool PREFETCH = !(BITS1 && K * D >= 160);
     float2 cyq[D];
+    float2 carry_cy[NLK ? NLK : 1];  // the head's operands of the row before: the tail's operands of this row
+    float carry_sum[NLK ? NLK : 1];  // the head's running column sum of the row before
     auto fetch = [&](auto IC) {
       constexpr int row = decltype(IC)::value;
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
-        const char *a = cy_base + aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d));
-        if constexpr (SINGLE) cyq[d].y = *reinterpret_cast<const float *>(a + 4);
-        else cyq[d] = *reinterpret_cast<const float2 *>(a);
+        if constexpr (d < 2 * NLK && (d & 1) == 0 && row >= 1) {
+          cyq[d] = carry_cy[d / 2];
+          return;
+        }
+        // (SINGLE uses y only, but reads the {cs, y} pair all the same: a 4-byte read of the 8-byte cells puts the
+        //  two frames of a half-wave on the same 16 of 32 banks -- SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles --
+        //  while the 8-byte read spreads them over 64)
+        cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d)));
       });
     };
     if constexpr (PREFETCH) fetch(std::integral_constant<int, 0>{});
@@ -474,11 +488,15 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         m2[0] = f2u(a2);
         sg[0] = s;
       }
+      static_for<NLK>([&](auto P) { carry_cy[P] = cyq[2 * P + 1]; });
       if constexpr (PREFETCH && i + 1 < K) fetch(std::integral_constant<int, i + 1>{});  // the next row's operands
       float cn[D];
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
-        cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
+        if constexpr (d < 2 * NLK && (d & 1) == 0 && i >= 1)
+          cn[d] = carry_sum[d / 2];  // the head added to this column in row i - 1 and kept the sum
+        else
+          cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
       });
       row_allreduce<1, LPF>(m1, m2, sg);
       // the parity leaves the last DPP stage in a register of its own: folded into the mask below, the compiler
@@ -516,7 +534,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       __builtin_amdgcn_sched_barrier(0);
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
-        *reinterpret_cast<float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
+        if constexpr (d < 2 * NLK && (d & 1) == 1 && i + 1 < K)
+          carry_sum[d / 2] = sum[d];  // the tail of this link continues it in row i + 1
+        else
+          *reinterpret_cast<float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
       });
       // The next row reads column sums that OTHER lanes have just written (column s + i is diagonal s - 1 of
       // row i + 1).  The hardware keeps LDS operations of a wavefront in order; the compiler must too: per
@@ -612,7 +633,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 namespace {
 
-template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false, typename PG = PairGaps<>>
+template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false, typename PG = PairGaps<>,
+          bool CHAIN = false>
 int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
@@ -640,10 +662,10 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
 #define CC_LAUNCH_S(V, O, S)                                                                                       \
   {                                                                                                                \
     e = hipFuncSetAttribute(                                                                                       \
-        reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S>),             \
+        reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S, CHAIN>),      \
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                                       \
     if (e == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S>), dim3(grid), dim3(256), lds, \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S, CHAIN>), dim3(grid), dim3(256), lds, \
                          stream, p, code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,    \
                          d_status, Bq);                                                                            \
   }

@@ -318,8 +318,9 @@ def test_fallback_kernels_stay_exact(env, expect):
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-1000:]
 
 
-@pytest.mark.parametrize("q,t,iters,log2b", [(8, 3, 20, 18), (6, 3, 10, 19), (5, 3, 10, 19)])
-def test_minsum_large_batch_is_deterministic_and_exact(q, t, iters, log2b):
+@pytest.mark.parametrize("q,t,iters,log2b,ebno", [(8, 3, 20, 18, 5.0), (6, 3, 10, 19, 5.0), (5, 3, 10, 19, 5.0),
+                                                  (8, 3, 20, 20, 4.0)])  # the last one is the bench workload
+def test_minsum_large_batch_is_deterministic_and_exact(q, t, iters, log2b, ebno):
     """Many frames per persistent lane group (the LDS staging of the next frame is reused hundreds of times):
     two launches agree bit for bit, a strided sample agrees with the oracle, and every converged frame satisfies
     H b^T = 0 (a size-independent property checked on the whole batch)."""
@@ -329,7 +330,7 @@ def test_minsum_large_batch_is_deterministic_and_exact(q, t, iters, log2b):
     B = 1 << log2b
     g = torch.Generator(device="cuda")
     g.manual_seed(q * 100 + t)
-    y = torch.empty((B, code.n), dtype=torch.float32, device="cuda").normal_(1.0, float(code.sigma(5.0)), generator=g)
+    y = torch.empty((B, code.n), dtype=torch.float32, device="cuda").normal_(1.0, float(code.sigma(ebno)), generator=g)
     a = code.correct_batch(y, want_L=True)
     b = code.correct_batch(y, want_L=True)
     for key in ("out", "L", "iters", "status"):
