@@ -242,7 +242,9 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     if (dev < 0 || dev >= ndev) return CC_ERR_INVALID_ARGUMENT;
   }
 
-  std::unique_ptr<cc_code> code(new (std::nothrow) cc_code());
+  // every early return below releases what has been allocated on the device so far (cc_code_destroy frees the
+  // device members, not only the struct)
+  std::unique_ptr<cc_code, void (*)(cc_code *)> code(new (std::nothrow) cc_code(), &cc_code_destroy);
   if (!code) return CC_ERR_OUT_OF_MEMORY;
   code->desc = *desc;
   code->device = dev;

@@ -184,7 +184,20 @@ struct McWorkspace {
   uint8_t *sent = nullptr, *msg = nullptr, *hard = nullptr;
   uint16_t *iters = nullptr;
   int32_t *status = nullptr, *nerr = nullptr;
+  // recorded behind the last work enqueued on the buffers: the lock only covers the ENQUEUE, so a later call on
+  // another stream first waits (on the device) for this event before it overwrites them
+  hipEvent_t done = nullptr;
+  int fence_in(hipStream_t stream) {
+    if (done) CC_HIP_TRY(hipStreamWaitEvent(stream, done, 0));
+    return CC_OK;
+  }
+  int fence_out(hipStream_t stream) {
+    if (!done) CC_HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    CC_HIP_TRY(hipEventRecord(done, stream));
+    return CC_OK;
+  }
   ~McWorkspace() {
+    if (done) (void)hipEventDestroy(done);
     for (void *p : {static_cast<void *>(llr), static_cast<void *>(sent), static_cast<void *>(msg),
                     static_cast<void *>(hard), static_cast<void *>(iters), static_cast<void *>(status),
                     static_cast<void *>(nerr)})
@@ -263,6 +276,8 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
   int rc = ensure_workspace(code, chunk);
   if (rc != CC_OK) return rc;
   McWorkspace &w = *code->mc;
+  rc = w.fence_in(stream);
+  if (rc != CC_OK) return rc;
   const int n = static_cast<int>(code->tab.n);
   for (size_t done = 0; done < frames; done += chunk) {
     const size_t m = frames - done < chunk ? frames - done : chunk;
@@ -284,7 +299,7 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "count kernel launch");
   }
-  return CC_OK;
+  return w.fence_out(stream);
 }
 
 
@@ -300,6 +315,8 @@ int mc_awgn(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, 
   int rc = ensure_workspace(code, chunk);
   if (rc != CC_OK) return rc;
   McWorkspace &w = *code->mc;
+  rc = w.fence_in(stream);
+  if (rc != CC_OK) return rc;
   const size_t n = code->tab.n;
   for (size_t done = 0; done < frames; done += chunk) {
     const size_t m = frames - done < chunk ? frames - done : chunk;
@@ -307,7 +324,7 @@ int mc_awgn(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, 
     rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, 1, d_llr + done * n, sent, w.msg, stream);
     if (rc != CC_OK) return rc;
   }
-  return CC_OK;
+  return w.fence_out(stream);
 }
 
 }  // namespace ccamd

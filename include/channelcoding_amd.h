@@ -55,7 +55,11 @@ typedef enum cc_family { CC_FAMILY_BCH = 0, CC_FAMILY_RS = 1 } cc_family;
 
 /* Algorithm tags: src/codes/hard_decision.h:15-24 and src/codes/soft_decision.h:20-73 */
 typedef enum cc_algorithm {
-  CC_ALG_PGZ = 0,    /* peterson_gorenstein_zierler_tag (the reference's default)  */
+  CC_ALG_PGZ = 0,    /* peterson_gorenstein_zierler_tag (the reference's default).  NOT run as Peterson-Gorenstein-
+                      * Zierler on the device: bounded-distance decoding = Berlekamp-Massey + "locator degree <= t"
+                      * (+ the two-trial erasure rule of bch.h:97-149 for BCH).  Same corrected words and failures
+                      * as the reference wherever its Gauss elimination is sound; it is not on 1-4 % of decodable
+                      * RS frames (linear_equation_system.h:24-35), which this decodes */
   CC_ALG_BM = 1,     /* berlekamp_massey_tag                                        */
   CC_ALG_EUKLID = 2, /* euklid_tag                                                  */
   CC_ALG_MS = 16,    /* min_sum_tag<It>                                             */
