@@ -84,6 +84,8 @@ _SIGNATURES = {
     "cc_extract_batch_u16_dev": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
     "cc_get_poly_u16": (C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
     "cc_q": (C.c_uint32, [_VP]),
+    "cc_diag_table": (C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                C.POINTER(C.c_uint32)]),
     "cc_kernel_info": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                  C.POINTER(C.c_uint32)]),
 }

@@ -1035,6 +1035,20 @@ int cc_awgn_llr_dev(const cc_code *code, double ebno_db, uint64_t seed, uint64_t
                  static_cast<hipStream_t>(stream));
 }
 
+int cc_diag_table(const cc_code *code, uint16_t *out, size_t cap, uint32_t *D, uint32_t *LPF, uint32_t *links) {
+  if (!code || !out) return -1;
+  if (code->matrix_only || code->wide || !code->custom_H.empty()) return 0;
+  const DiagGeometry *g = diag_geometry(code->tab);
+  if (!g) return 0;
+  const std::vector<uint16_t> t = build_diag_table(code->tab, g->D, g->LPF, g->np, g->gap);
+  if (t.empty() || t.size() > cap) return -1;
+  std::copy(t.begin(), t.end(), out);
+  if (D) *D = static_cast<uint32_t>(g->D);
+  if (LPF) *LPF = static_cast<uint32_t>(g->LPF);
+  if (links) *links = static_cast<uint32_t>(g->np);
+  return static_cast<int>(t.size());
+}
+
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
                    uint32_t *threads_per_workgroup, uint32_t *lds_bytes) {
   if (!code) return CC_ERR_INVALID_ARGUMENT;

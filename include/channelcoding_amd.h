@@ -250,6 +250,12 @@ uint32_t cc_q(const cc_code *code);
 int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames_per_workgroup,
                    uint32_t *threads_per_workgroup, uint32_t *lds_bytes);
 
+/* The deal of the diagonal min-sum kernel for this code (host logic, works on CC_DEVICE_NONE handles): D slots x
+ * LPF lanes of row-0 support positions, slot-major (0xFFFF = empty slot of a "partial" geometry); *links = number of
+ * chained slot pairs (slots 2p and 2p + 1 hold diagonals s and s + 1 in every lane).  Returns the number of entries
+ * written, 0 if the code has no diagonal geometry, < 0 on error. */
+int cc_diag_table(const cc_code *code, uint16_t *out, size_t cap, uint32_t *D, uint32_t *LPF, uint32_t *links);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,23 +114,48 @@ public:
 };
 
 namespace math {
-// GF(2^q) element as a value type (galois.h:89-267): enough for RS symbol I/O and printing.
-template <long prime, long power> class ef_element;
-template <long Power> class ef_element<2, Power> {
-  static_assert(Power >= 1 && Power <= 8, "q <= 8");
+// math::modular_polynomial<> (galois.h:23-25) and the default per field size (galois.h:57-67): defaults exist for
+// q <= 8; a field GF(2^q) with q = 9 .. 15 has to be named by the caller, exactly as in the reference --
+//     namespace math { namespace detail {
+//     template <> struct default_modular_polynomial<10> { using type = ::math::modular_polynomial<0x409>; };
+//     } }
+// before the first use of cyclic::primitive_bch<10, ...> / cyclic::rs<10, ...> / math::ef_element<2, 10>.
+template <uint16_t poly> struct modular_polynomial {
+  static constexpr uint16_t value = poly;
+};
+namespace detail {
+template <unsigned q> struct default_modular_polynomial {
+  static_assert(q > 0, "GF(2^0) does not make sense. Choose q > 0.");
+  static_assert(q < 9, "modular polynomials for GF(2^q), q > 8 have to be specified manually: specialise "
+                       "math::detail::default_modular_polynomial<q>");
+  static constexpr uint16_t table[9] = {0, 0x3, 0x7, 0xb, 0x13, 0x25, 0x43, 0x83, 0x11d};  // galois.h:18-20
+  using type = ::math::modular_polynomial<table[q < 9 ? q : 0]>;
+};
+template <unsigned q> constexpr uint16_t default_modular_polynomial<q>::table[9];
+}  // namespace detail
+
+// GF(2^q) element as a value type (galois.h:89-267): enough for symbol I/O and printing.  storage_type is uint8_t
+// for q <= 8 and uint16_t beyond (galois.h:44-53).
+template <long prime, long power, typename Modular_Polynomial = typename detail::default_modular_polynomial<power>::type>
+class ef_element;
+template <long Power, typename Mp> class ef_element<2, Power, Mp> {
+  static_assert(Power >= 1 && Power <= 15, "q <= 15");
   static constexpr unsigned size = 1u << Power;
+
+public:
+  using storage_type = typename std::conditional<(Power > 8), uint16_t, uint8_t>::type;
+  static constexpr unsigned mod_polynomial = Mp::value;
+
+private:
   struct tables {
-    uint8_t exp[2 * size], log[2 * size];
-    tables() {
-      static constexpr unsigned mp[9] = {0, 0x3, 0x7, 0xb, 0x13, 0x25, 0x43, 0x83, 0x11d};  // galois.h:18-20
-      for (auto &e : exp) e = 0;
-      for (auto &l : log) l = 0;
+    std::vector<storage_type> exp, log;
+    tables() : exp(2 * size, 0), log(2 * size, 0) {
       unsigned v = 1;
       for (unsigned p = 0; p + 1 < size; ++p) {
-        log[v] = log[v + size] = static_cast<uint8_t>(p);
-        exp[p] = exp[p + size - 1] = static_cast<uint8_t>(v);
+        log[v] = log[v + size] = static_cast<storage_type>(p);
+        exp[p] = exp[p + size - 1] = static_cast<storage_type>(v);
         v <<= 1;
-        if (v & size) v ^= mp[Power];
+        if (v & size) v ^= mod_polynomial;
       }
       exp[size - 1] = exp[2 * size - 2] = 1;
     }
@@ -139,10 +164,9 @@ template <long Power> class ef_element<2, Power> {
     static const tables t;
     return t;
   }
-  uint8_t value = 0;
+  storage_type value = 0;
 
 public:
-  using storage_type = uint8_t;
   static constexpr size_t digits = Power;
   ef_element() = default;
   explicit ef_element(const storage_type &v) : value(v) {
@@ -150,7 +174,7 @@ public:
   }
   static ef_element from_power(unsigned p) { return ef_element(tab().exp[p % size]); }  // galois.h:182-184
   unsigned power() const { return tab().log[value]; }
-  ef_element operator+(const ef_element &r) const { return ef_element(static_cast<uint8_t>(value ^ r.value)); }
+  ef_element operator+(const ef_element &r) const { return ef_element(static_cast<storage_type>(value ^ r.value)); }
   ef_element operator*(const ef_element &r) const {
     if (!value || !r.value) return ef_element(0);
     return ef_element(tab().exp[power() + r.power()]);
@@ -212,8 +236,34 @@ struct code_deleter {
 template <typename T> struct to_byte {
   static uint8_t get(const T &v) { return static_cast<uint8_t>(v); }
 };
-template <long P> struct to_byte<math::ef_element<2, P>> {
-  static uint8_t get(const math::ef_element<2, P> &v) { return static_cast<uint8_t>(v); }
+template <long P, typename Mp> struct to_byte<math::ef_element<2, P, Mp>> {
+  static uint8_t get(const math::ef_element<2, P, Mp> &v) { return static_cast<uint8_t>(static_cast<unsigned>(v)); }
+};
+template <typename S, typename T> struct to_symbol {
+  static S get(const T &v) { return static_cast<S>(v); }
+};
+template <typename S, long P, typename Mp> struct to_symbol<S, math::ef_element<2, P, Mp>> {
+  static S get(const math::ef_element<2, P, Mp> &v) { return static_cast<S>(static_cast<unsigned>(v)); }
+};
+// symbol type and single-call entry points by field size: bytes for q <= 8, 16 bits beyond (the _u16 entry points)
+template <bool Wide> struct symbol_io;
+template <> struct symbol_io<false> {
+  using symbol = uint8_t;
+  static int encode(const cc_code *c, const symbol *m, symbol *w) { return cc_encode_batch(c, m, w, 1); }
+  static int extract(const cc_code *c, const symbol *w, symbol *m) { return cc_extract_batch(c, w, m, 1); }
+  static int correct(const cc_code *c, const symbol *in, const uint16_t *er, const uint32_t *off, symbol *out, int32_t *nerr,
+                     int32_t *st) {
+    return cc_correct_hard_batch(c, in, er, off, out, nerr, st, 1);
+  }
+};
+template <> struct symbol_io<true> {
+  using symbol = uint16_t;
+  static int encode(const cc_code *c, const symbol *m, symbol *w) { return cc_encode_batch_u16(c, m, w, 1); }
+  static int extract(const cc_code *c, const symbol *w, symbol *m) { return cc_extract_batch_u16(c, w, m, 1); }
+  static int correct(const cc_code *c, const symbol *in, const uint16_t *er, const uint32_t *off, symbol *out, int32_t *nerr,
+                     int32_t *st) {
+    return cc_correct_hard_batch_u16(c, in, er, off, out, nerr, st, 1);
+  }
 };
 inline const char *failure_text(int st) {
   switch (st) {
@@ -244,7 +294,10 @@ class code_base {
   static_assert(N == (1u << q) - 1, "shortened codes are not supported by the device path");
 
 public:
-  using Element = math::ef_element<2, q>;
+  using Element = math::ef_element<2, q>;  // (q > 8: through default_modular_polynomial<q>, see namespace math)
+  static constexpr bool wide = q > 8;      // 16-bit symbols, the _u16 entry points
+  using io = detail::symbol_io<wide>;
+  using symbol = typename io::symbol;
   static constexpr unsigned n = N;
   static constexpr unsigned t = correction_capability<Capability>::value;
   static constexpr bool soft = std::is_base_of<soft_decision_tag, Algorithm>::value;
@@ -271,6 +324,7 @@ public:
     d.beta = Algorithm::beta;
     d.stop_rule = stop;
     d.device = device;
+    if (wide) d.modular_polynomial = Element::mod_polynomial;
     cc_code *c = nullptr;
     detail::check(cc_code_create(&d, &c), "cc_code_create");
     handle.reset(c, detail::code_deleter());
@@ -316,38 +370,40 @@ public:
       os << "Source code word has wrong length (" << a.size() << "). Expected " << l;
       throw std::runtime_error(os.str());
     }
-    std::vector<uint8_t> msg(l), cw(n);
-    std::transform(a.begin(), a.end(), msg.begin(),
-                   [](const typename InputSequence::value_type &e) { return detail::to_byte<typename InputSequence::value_type>::get(e); });
-    const int rc = cc_encode_batch(handle.get(), msg.data(), cw.data(), 1);
+    std::vector<symbol> msg(l), cw(n);
+    std::transform(a.begin(), a.end(), msg.begin(), [](const typename InputSequence::value_type &e) {
+      return detail::to_symbol<symbol, typename InputSequence::value_type>::get(e);
+    });
+    const int rc = io::encode(handle.get(), msg.data(), cw.data());
     if (rc == CC_ERR_NOT_IN_FIELD) throw std::runtime_error("Value is not an element of the field.");
     detail::check(rc, "cc_encode_batch");
-    for (uint8_t v : cw) *out++ = typename InputSequence::value_type(v);
+    for (symbol v : cw) *out++ = typename InputSequence::value_type(v);
   }
 
   // ---- correct, cyclic.h:331-344 ----
-  template <typename Return_type = uint8_t, typename InputSequence>
+  template <typename Return_type = symbol, typename InputSequence>
   std::vector<Return_type> correct(const InputSequence &b, const std::vector<unsigned> &erasures = std::vector<unsigned>()) const {
-    const std::vector<uint8_t> w = correct_bytes(b, erasures);
+    const std::vector<symbol> w = correct_symbols(b, erasures);
     std::vector<Return_type> r;
     r.reserve(n);
-    for (uint8_t v : w) r.push_back(Return_type(v));
+    for (symbol v : w) r.push_back(Return_type(v));
     return r;
   }
 
   // ---- decode, cyclic.h:313-327 ----
   template <typename InputSequence, typename Return_type = typename InputSequence::value_type>
   std::vector<Return_type> decode(const InputSequence &b, const std::vector<unsigned> &erasures = std::vector<unsigned>()) const {
-    const std::vector<uint8_t> w = correct_bytes(b, erasures);
-    std::vector<uint8_t> msg(l);
-    detail::check(cc_extract_batch(handle.get(), w.data(), msg.data(), 1), "cc_extract_batch");
+    const std::vector<symbol> w = correct_symbols(b, erasures);
+    std::vector<symbol> msg(l);
+    detail::check(io::extract(handle.get(), w.data(), msg.data()), "cc_extract_batch");
     std::vector<Return_type> r;
     r.reserve(l);
-    for (uint8_t v : msg) r.push_back(Return_type(v));
+    for (symbol v : msg) r.push_back(Return_type(v));
     return r;
   }
 
   // ---- batch forms (new): B frames of n symbols / soft values, frame-contiguous ----
+  // (q <= 8 only: a q > 8 code batches through cc_correct_hard_batch_u16 / cc_encode_batch_u16 on handle.get())
   batch_result correct_batch(const uint8_t *symbols, size_t B) const {
     batch_result r;
     r.words.resize(B * n);
@@ -402,7 +458,7 @@ public:
 
 private:
   template <typename InputSequence>
-  std::vector<uint8_t> correct_bytes(const InputSequence &b, const std::vector<unsigned> &erasures) const {
+  std::vector<symbol> correct_symbols(const InputSequence &b, const std::vector<unsigned> &erasures) const {
     using V = typename InputSequence::value_type;
     if (b.size() != n) {  // cyclic.h:213-218
       std::ostringstream os;
@@ -415,27 +471,38 @@ private:
     const uint32_t off[2] = {0, static_cast<uint32_t>(er.size())};
     const uint16_t *erp = er.empty() ? nullptr : er.data();
     const uint32_t *offp = er.empty() ? nullptr : off;
-    std::vector<uint8_t> out(n);
+    std::vector<symbol> out(n);
     int32_t status = 0, nerr = 0;
     int rc;
     if (std::is_signed<V>::value) {  // signed value_type: soft value, bit = (x < 0)  (cyclic.h:163-173,:220-222)
-      std::vector<float> y(n);
-      std::transform(b.begin(), b.end(), y.begin(), [](const V &v) { return as_float(v); });
-      if (soft) {
-        rc = cc_correct_soft_batch(handle.get(), y.data(), erp, offp, out.data(), nullptr, nullptr, &status, 1);
-      } else {
-        rc = cc_correct_hard_f32_batch(handle.get(), y.data(), erp, offp, out.data(), &nerr, &status, 1);
-      }
+      rc = correct_signed(b, erp, offp, out, &nerr, &status, std::integral_constant<bool, wide>());
     } else {
       if (soft) throw std::runtime_error("min-sum needs a signed (soft) input sequence");
-      std::vector<uint8_t> sym(n);
-      std::transform(b.begin(), b.end(), sym.begin(), [](const V &v) { return detail::to_byte<V>::get(v); });
-      rc = cc_correct_hard_batch(handle.get(), sym.data(), erp, offp, out.data(), &nerr, &status, 1);
+      std::vector<symbol> sym(n);
+      std::transform(b.begin(), b.end(), sym.begin(), [](const V &v) { return detail::to_symbol<symbol, V>::get(v); });
+      rc = io::correct(handle.get(), sym.data(), erp, offp, out.data(), &nerr, &status);
       if (rc == CC_ERR_NOT_IN_FIELD) throw std::runtime_error("Value is not an element of the field.");
     }
     detail::check(rc, "correct");
     if (status != CC_FRAME_OK) throw decoding_failure(detail::failure_text(status));
     return out;
+  }
+  template <typename InputSequence>
+  int correct_signed(const InputSequence &b, const uint16_t *erp, const uint32_t *offp, std::vector<symbol> &out, int32_t *nerr,
+                     int32_t *status, std::false_type) const {
+    using V = typename InputSequence::value_type;
+    std::vector<float> y(n);
+    std::transform(b.begin(), b.end(), y.begin(), [](const V &v) { return as_float(v); });
+    if (soft) return cc_correct_soft_batch(handle.get(), y.data(), erp, offp, out.data(), nullptr, nullptr, status, 1);
+    return cc_correct_hard_f32_batch(handle.get(), y.data(), erp, offp, out.data(), nerr, status, 1);
+  }
+  template <typename InputSequence>
+  int correct_signed(const InputSequence &b, const uint16_t *erp, const uint32_t *offp, std::vector<symbol> &out, int32_t *nerr,
+                     int32_t *status, std::true_type) const {  // q > 8: the sign bits are the word (all in GF(2) of GF(2^q))
+    using V = typename InputSequence::value_type;
+    std::vector<symbol> sym(n);
+    std::transform(b.begin(), b.end(), sym.begin(), [](const V &v) { return static_cast<symbol>(as_float(v) < 0.0f); });
+    return io::correct(handle.get(), sym.data(), erp, offp, out.data(), nerr, status);
   }
   template <typename V> static typename std::enable_if<std::is_arithmetic<V>::value, float>::type as_float(const V &v) {
     return static_cast<float>(v);

@@ -8,6 +8,21 @@
 
 #include "channelcoding_amd/cyclic.hpp"
 
+// GF(2^10) and GF(2^9) as the reference names them (galois.h:57-67: no default beyond q = 8)
+namespace math {
+namespace detail {
+template <> struct default_modular_polynomial<10> {
+  using type = ::math::modular_polynomial<0x409>;
+};
+template <> struct default_modular_polynomial<9> {
+  using type = ::math::modular_polynomial<0x211>;
+};
+template <> struct default_modular_polynomial<11> {
+  using type = ::math::modular_polynomial<0x803>;  // x^11 + x + 1: reducible, so not primitive
+};
+}  // namespace detail
+}  // namespace math
+
 template <typename C1, typename C2> static void expect_equal(const char *what, const C1 &a, const C2 &b) {
   if (a.size() != b.size()) throw std::runtime_error(std::string(what) + ": size mismatch");
   for (size_t i = 0; i < a.size(); i++)
@@ -145,6 +160,69 @@ int main() try {
     });
     const auto ok110 = min_sum<float, uint8_t>(one, std::vector<float>({-5.0f, -5.0f, 1.0f}), min_sum_tag<3>());
     expect_equal("free min_sum, GF(2) parity rule", std::vector<uint8_t>({1, 1, 0}), std::get<0>(ok110));
+  }
+  {  // q > 8: 16-bit symbols through the _u16 entry points, modular polynomial named by the caller
+    using RS = cyclic::rs<10, errors<4>, cyclic::berlekamp_massey_tag>;
+    using Element = RS::Element;
+    static_assert(std::is_same<Element::storage_type, uint16_t>::value && RS::n == 1023 && RS::wide, "wide field");
+    RS code;
+    std::vector<Element> msg;
+    for (unsigned j = 0; j < RS::n - 8; j++) msg.push_back(Element::from_power(7 * j + 3));
+    std::vector<Element> cw;
+    code.encode(msg, std::back_inserter(cw));
+    if (cw.size() != 1023) throw std::runtime_error("wide encode length");
+    std::vector<Element> rx(cw);
+    rx[5] = rx[5] + Element::from_power(600);
+    rx[400] = rx[400] + Element(1);
+    rx[1000] = Element(0);
+    rx[1022] = rx[1022] + Element::from_power(1);
+    expect_equal("rs<10, errors<4>> correct", cw, code.correct<Element>(rx));
+    expect_equal("rs<10, errors<4>> decode", msg, code.decode(rx));
+    rx[7] = rx[7] + Element(1);
+    rx[8] = rx[8] + Element(1);  // six errors: outside the capability (a miscorrection is possible, equality is not)
+    try {
+      if (code.correct<Element>(rx) == cw) throw std::runtime_error("rs<10>: six errors corrected?");
+      std::printf("ok   rs<10, errors<4>> six errors (another word)\n");
+    } catch (const decoding_failure &) {
+      std::printf("ok   rs<10, errors<4>> six errors (decoding_failure)\n");
+    }
+    std::vector<Element> er(cw);
+    const std::vector<unsigned> erasures = {0, 17, 512, 1021};
+    for (auto e : erasures) er.at(e) = Element(0);
+    er[300] = er[300] + Element::from_power(9);
+    er[301] = er[301] + Element::from_power(10);
+    expect_equal("rs<10> 4 erasures + 2 errors", cw, code.correct<Element>(er, erasures));
+
+    cyclic::primitive_bch<9, errors<3>, cyclic::euklid_tag> bch;
+    const unsigned l9 = 511 - 27;
+    if (bch.n != 511 || bch.to_string() != "(511, 484, 7)-EUKLID") throw std::runtime_error("bch<9>: " + bch.to_string());
+    std::vector<uint16_t> m9(l9), w9;
+    for (unsigned j = 0; j < l9; j++) m9[j] = (j * 2654435761u >> 13) & 1;
+    bch.encode(m9, std::back_inserter(w9));
+    std::vector<uint16_t> r9(w9);
+    r9[0] ^= 1;
+    r9[255] ^= 1;
+    r9[510] ^= 1;
+    expect_equal("primitive_bch<9, errors<3>> correct", w9, bch.correct(r9));
+    expect_equal("primitive_bch<9, errors<3>> decode", m9, bch.decode(r9));
+    std::vector<float> soft9(w9.size());
+    for (size_t j = 0; j < w9.size(); j++) soft9[j] = r9[j] ? -1.0f : 1.0f;  // signed input: bit = (x < 0)
+    expect_equal("primitive_bch<9> signed input", w9, bch.correct<uint16_t>(soft9));
+    r9[3] = 2;  // a non-binary field element in a BCH word is accepted (the field is GF(2^9)), 512 is not an element
+    r9[4] = 512;
+    try {
+      bch.correct(r9);
+      throw std::logic_error("512 accepted in GF(2^9)");
+    } catch (const std::runtime_error &e) {
+      if (std::string(e.what()) != "Value is not an element of the field.") throw;
+      std::printf("ok   GF(2^9) range check\n");
+    }
+    try {
+      cyclic::rs<11, errors<2>> bad;
+      throw std::logic_error("reducible modular polynomial accepted");
+    } catch (const std::runtime_error &e) {
+      std::printf("ok   non-primitive modular polynomial refused (%s)\n", e.what());
+    }
   }
   std::printf("ALL OK\n");
   return 0;

@@ -190,3 +190,35 @@ def test_wide_field_code_constants_match_reference_vectors():
     for q, poly in ((9, 0x211), (10, 0x409), (11, 0x805), (12, 0x1053), (13, 0x201B), (14, 0x4443), (15, 0x8003)):
         c = cc.rs(q, cc.errors(2), cc.euklid_tag(), device=capi.DEVICE_NONE, modular_polynomial=poly)
         assert c.n == (1 << q) - 1 and c.k == 4 and c.to_string() == "(%d, %d, 6)-EUKLID" % (c.n, c.n - 4)
+
+
+def test_diagonal_deal_is_a_partition_with_chained_pairs():
+    """Host logic of the diagonal min-sum kernel (csrc/minsum_diag.hip): the row-0 support of every code with a
+    diagonal geometry is dealt to D slots x LPF lanes exactly once; in a geometry with links, slots 2p and 2p + 1
+    of EVERY lane hold adjacent diagonals s and s + 1 (what lets the kernel pass a column from one to the other
+    through registers: csrc/minsum_diag_impl.hpp, CHAIN)."""
+    import ctypes as C
+    lib = capi.lib()
+    seen_links = 0
+    for q, ts in ((4, (1, 2, 3)), (5, (1, 2, 3, 5)), (6, (1, 2, 3, 4)), (7, (1, 2, 3, 4)), (8, (1, 2, 3, 4))):
+        for t in ts:
+            code = cc.primitive_bch(q, cc.errors(t), cc.min_sum_tag(5), device=capi.DEVICE_NONE)
+            out = np.zeros(1024, np.uint16)
+            D, LPF, links = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            m = lib.cc_diag_table(code._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(D), C.byref(LPF),
+                                  C.byref(links))
+            assert m == D.value * LPF.value and m > 0, (q, t, m)
+            table = out[:m].reshape(D.value, LPF.value)
+            H = code.H()
+            support = [j for j in range(code.n) if H[0, j]]
+            dealt = sorted(int(v) for v in table.ravel() if v != 0xFFFF)
+            assert dealt == support, (q, t)
+            for p in range(links.value):
+                assert np.array_equal(table[2 * p + 1].astype(int), table[2 * p].astype(int) + 1), (q, t, p)
+            seen_links += links.value
+            again = np.zeros(1024, np.uint16)
+            lib.cc_diag_table(code._h, again.ctypes.data_as(C.c_void_p), again.size, None, None, None)
+            assert np.array_equal(out, again)  # deterministic
+    assert seen_links >= 10  # the headline code alone has two
+    rs = cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag(), device=capi.DEVICE_NONE)
+    assert lib.cc_diag_table(rs._h, out.ctypes.data_as(C.c_void_p), out.size, None, None, None) == 0
