@@ -51,11 +51,14 @@ __host__ __device__ inline ChunkLayout chunk_layout(int t2, int fpw) {
   return c;
 }
 
-template <bool FLOAT_IN, int FPW>
+// PRE: the syndromes come from bitslice.hip ([j][group of 32 frames][32], FPW == 32) and `out` already holds the
+// received words: stage A only fetches them, stage C only patches the located errors.
+template <bool FLOAT_IN, int FPW, bool PRE = false>
 __global__ void __launch_bounds__(256, 4)
 algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__restrict__ in_raw,
                        uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
-                       unsigned long long B) {
+                       unsigned long long B, const uint8_t *__restrict__ synd = nullptr, unsigned long long G = 0) {
+  static_assert(!PRE || FPW == 32, "a chunk is one group of the bit-plane layout");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t *ex = smem;                                            // [1024]
   uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);     // [256]
@@ -123,6 +126,23 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
     // constants, so a term costs one add, one table read and one XOR.  A zero symbol parks lt on the zero
     // part of the table (log 0 = 512) and advances by nn, which the wrap undoes.
     unsigned long long smask = 0;  // frames with a non-zero syndrome
+    if (PRE) {
+      const int f = lane & 31;
+      const uint8_t *src = synd + chunk * 32 + 4 * (f & 7) + (f >> 3);  // frame 8i + k of the group: byte 4k + i
+      uint32_t any = 0;
+      for (int j = lane >> 5; j < t2; j += 2) {
+        const uint32_t v = src[static_cast<unsigned long long>(j) * G * 32];
+        SV[j * FPW + f] = static_cast<uint8_t>(v);
+        SL[j * FPW + f] = lg2[v];
+        any |= v;
+      }
+      const unsigned long long m = __ballot(any != 0 && f < frames);
+      smask = dbg_stop == 1 ? 0ull : ((m | (m >> 32)) & 0xFFFFFFFFull);
+      if (lane < frames && !((smask >> lane) & 1ull)) {  // a codeword: done (cyclic.h:225-231)
+        if (nerr_out) nerr_out[first + lane] = 0;
+        if (status_out) status_out[first + lane] = CC_FRAME_OK;
+      }
+    } else {
     constexpr int PF = 3;          // frames in flight: the stage is latency-bound otherwise (255 B per frame)
     uint32_t symq[PF][4];
 #pragma unroll
@@ -183,6 +203,7 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           }
         }
       }
+    }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -258,8 +279,8 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
     unsigned long long todo = smask;
     int s0 = pop(todo), s1 = pop(todo);
     uint32_t q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
-    if (s0 >= 0) load_symbols(first + s0, q0);
-    if (s1 >= 0) load_symbols(first + s1, q1);
+    if (!PRE && s0 >= 0) load_symbols(first + s0, q0);
+    if (!PRE && s1 >= 0) load_symbols(first + s1, q1);
     while (s0 >= 0) {
       const int s = s0;
       const unsigned long long frame = first + s;
@@ -271,7 +292,7 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
       }
       s0 = s1;
       s1 = pop(todo);
-      if (s1 >= 0) load_symbols(first + s1, q1);
+      if (!PRE && s1 >= 0) load_symbols(first + s1, q1);
       int status = CC_FRAME_OK, nerr = 0;
       {
         const int deg = DEG[s], len = LEN[s];
@@ -384,8 +405,13 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
       }
       const bool ok = status == CC_FRAME_OK;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (valid[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
+      for (int c = 0; c < 4; ++c) {
+        if (PRE) {
+          if (ok && corr[c]) out[frame * n + lane + 64 * c] ^= static_cast<uint8_t>(corr[c]);
+        } else if (valid[c]) {
+          out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
+        }
+      }
       if (lane == 0) {
         if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
         if (status_out) status_out[frame] = status;
@@ -449,9 +475,49 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
   return CC_OK;
 }
 
+// syndromes on bit planes (bitslice.hip), then the chunk kernel from stage B on
+static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
+                                  int32_t *d_status, size_t B, hipStream_t stream) {
+  const int t2 = static_cast<int>(code->tab.roots.size());
+  const unsigned long long G = (B + 31) / 32;
+  const size_t plane_bytes = static_cast<size_t>(G) * code->tab.n * 32, synd_bytes = static_cast<size_t>(G) * t2 * 32;
+  uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + synd_bytes, stream));
+  uint8_t *d_synd = ws + plane_bytes;
+  int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
+  if (rc == CC_OK) {
+    constexpr int FPW = 32;
+    const size_t lds = 1792 + 4 * static_cast<size_t>(chunk_layout(t2, FPW).bytes);
+    const unsigned long long blocks_needed = (G + 3) / 4;
+    unsigned long long per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
+    const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
+    static const int dbg_stop = [] {
+      const char *e = std::getenv("CC_AMD_ALG_STOP");
+      return e ? std::atoi(e) : 0;
+    }();
+    const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
+    const unsigned long long Bq = B;
+    hipError_t e = hipSuccess;
+    if (lds > 48 * 1024)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&algebraic_chunk_kernel<false, FPW, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((algebraic_chunk_kernel<false, FPW, true>), dim3(grid), dim3(256), lds, stream, code->d_alg, alg_arg,
+                         static_cast<const void *>(nullptr), d_out, d_nerr, d_status, Bq, d_synd, G);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) rc = hip_fail(e, "algebraic chunk kernel launch");
+  }
+  (void)hipFreeAsync(ws, stream);
+  return rc;
+}
+
 int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
                            int32_t *d_status, size_t B, hipStream_t stream) {
   if (B == 0) return CC_OK;
+  if (bitslice_supported(code)) return launch_chunk_bitsliced(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
   static const int fpw = [] {
     const char *e = std::getenv("CC_AMD_CHUNK_FPW");
     return e ? std::atoi(e) : 32;
