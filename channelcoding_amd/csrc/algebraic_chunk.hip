@@ -128,10 +128,12 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
     unsigned long long smask = 0;  // frames with a non-zero syndrome
     if (PRE) {
       const int f = lane & 31;
-      const uint8_t *src = synd + chunk * 32 + 4 * (f & 7) + (f >> 3);  // frame 8i + k of the group: byte 4k + i
+      // [block of 64 groups][j][group in block][32]; frame 8i + k of the group: byte 4k + i
+      const uint8_t *src = synd + ((chunk >> 6) * t2 * 64 + (chunk & 63)) * 32 + 4 * (f & 7) + (f >> 3);
       uint32_t any = 0;
+#pragma unroll 4
       for (int j = lane >> 5; j < t2; j += 2) {
-        const uint32_t v = src[static_cast<unsigned long long>(j) * G * 32];
+        const uint32_t v = src[j * 2048];
         SV[j * FPW + f] = static_cast<uint8_t>(v);
         SL[j * FPW + f] = lg2[v];
         any |= v;
@@ -225,7 +227,18 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
         // discrepancy :139-141; lambda_m = 0 (log 512) beyond its degree, so no per-lane bound is needed
         uint32_t d = SV[i * FPW + f];
         const int mm = i < lw ? i : lw;
-        for (int m = 1; m <= mm; ++m) d ^= ex[LL[m * FPW + f] + SL[(i - m) * FPW + f]];
+        // lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of four adds zeros
+        for (int m0 = 1; m0 <= mm; m0 += 4) {
+          uint32_t la[4], sa[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = m0 + u < nc ? m0 + u : nc - 1;
+            la[u] = LL[m * FPW + f];
+            sa[u] = SL[(i - m > 0 ? i - m : 0) * FPW + f];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) d ^= ex[la[u] + sa[u]];
+        }
         const bool upd = mine && d != 0;
         const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
         const uint32_t ld = lg2[d];
@@ -302,6 +315,7 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           CSL[lane] = SL[lane * FPW + s];
         }
         for (int m = lane; m < nc; m += 64) CLL[m] = LL[m * FPW + s];
+        const uint32_t cll = LL[(lane < nc ? lane : 0) * FPW + s];  // log lambda_lane, read by readlane (nc <= 64)
         // the PGZ tag runs as bounded-distance decoding: locator degree within capability
         if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
         if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
@@ -311,8 +325,9 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
         uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
         if (status == CC_FRAME_OK) {
           uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
+#pragma unroll 2
           for (int m = 0; m <= deg; ++m) {
-            const uint32_t lm = CLL[m];
+            const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               acc[c] ^= ex[lm + e[c]];
@@ -331,6 +346,11 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           }
           nerr = static_cast<int>(count);
           if (nerr != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
+          if (PRE && status == CC_FRAME_OK) {  // the symbols to patch: fetched now, needed after the error values
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (isroot[c]) sym[c] = out[frame * n + lane + 64 * c];
+          }
         }
         if (dbg_stop == 3) status = CC_FRAME_LOCATOR;
 
@@ -340,12 +360,13 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           for (int c = 0; c < 4; ++c)
             if (isroot[c]) RP[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
           uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg
+#pragma unroll 2
           for (int m = 0; m <= deg; ++m) {
-            const uint32_t lm = CLL[m];
+            const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
             const bool in = lane >= m && lane < deg && lane - m < t2;
             om ^= in ? ex[lm + CSL[in ? lane - m : 0]] : 0u;
           }
-          OML[lane] = lg2[om];
+          const uint32_t oml = lg2[om];
           uint32_t y = 0;
           if (lane < deg) {
             const uint32_t p = RP[lane];
@@ -353,14 +374,16 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
             uint32_t x2 = 2 * xi;
             x2 = umin32(x2, x2 - static_cast<uint32_t>(nn));
             uint32_t num = 0, den = 0, e = 0;
+#pragma unroll 2
             for (int j = 0; j < deg; ++j) {  // omega(X^-1)
-              num ^= ex[OML[j] + e];
+              num ^= ex[__builtin_amdgcn_readlane(oml, j) + e];
               e += xi;
               e = umin32(e, e - static_cast<uint32_t>(nn));
             }
             e = 0;
+#pragma unroll 2
             for (int m = 1; m <= deg; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
-              den ^= ex[CLL[m] + e];
+              den ^= ex[__builtin_amdgcn_readlane(cll, m) + e];
               e += x2;
               e = umin32(e, e - static_cast<uint32_t>(nn));
             }
@@ -407,11 +430,353 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (PRE) {
-          if (ok && corr[c]) out[frame * n + lane + 64 * c] ^= static_cast<uint8_t>(corr[c]);
+          if (ok && corr[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ corr[c]);
         } else if (valid[c]) {
           out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
         }
       }
+      if (lane == 0) {
+        if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
+        if (status_out) status_out[frame] = status;
+      }
+      __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next frame
+    }
+  }
+}
+
+
+// ================= split form behind the bit-plane syndromes (bitslice.hip) =================
+// Stage B is bound by the LDS pipe (eight LDS operations per coefficient step) and wants every lane busy: 64
+// frames per wavefront, 17 KB of LDS per wavefront, two wavefronts per SIMD.  Stage C walks the dirty frames one at
+// a time through chains of dependent table look-ups and wants many wavefronts: its own kernel with 0.3 KB of LDS
+// per wavefront.  lambda (logs), deg / L and the dirty masks travel through HBM (70 B per frame).
+struct BmLayout {
+  int SL, LL, BL, SV, LV, bytes;
+};
+__host__ __device__ inline BmLayout bm_layout(int t2) {
+  BmLayout c;
+  const int nc = t2 + 1;
+  c.SL = 0;                     // u16 [t2][64]  log S_j
+  c.LL = c.SL + 2 * t2 * 64;    // u16 [nc][64]  log lambda_m
+  c.BL = c.LL + 2 * nc * 64;    // u16 [nc][64]  log b_m
+  c.SV = c.BL + 2 * nc * 64;    // u8  [t2][64]  S_j
+  c.LV = c.SV + t2 * 64;        // u8  [nc][64]  lambda_m
+  c.bytes = (c.LV + nc * 64 + 15) & ~15;
+  return c;
+}
+
+__global__ void __launch_bounds__(256, 2)
+chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
+                uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
+                int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t *ex = smem;                                         // [1024]
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
+  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
+  __syncthreads();
+  constexpr int FPW = 64;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, f = lane;
+  const int nn = T->n, t2 = T->nroots, nc = t2 + 1;
+  const BmLayout lay = bm_layout(t2);
+  uint8_t *base = smem + 1536 + wid * lay.bytes;
+  uint16_t *SL = reinterpret_cast<uint16_t *>(base + lay.SL);
+  uint16_t *LL = reinterpret_cast<uint16_t *>(base + lay.LL);
+  uint16_t *BL = reinterpret_cast<uint16_t *>(base + lay.BL);
+  uint8_t *SV = base + lay.SV, *LV = base + lay.LV;
+
+  const unsigned long long nchunks = (B + FPW - 1) / FPW;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * FPW;
+    const int frames = static_cast<int>((B - first) < static_cast<unsigned long long>(FPW) ? (B - first) : FPW);
+    // syndromes of frame 8i + k of group g: byte 4k + i of [block of 64 groups][j][group in block][32]
+    const unsigned long long group = 2 * chunk + (f >> 5);
+    const int fi = f & 31;
+    const uint8_t *src = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+    uint32_t any = 0;
+#pragma unroll 8
+    for (int j = 0; j < t2; ++j) {
+      const uint32_t v = src[j * 2048];
+      SV[j * FPW + f] = static_cast<uint8_t>(v);
+      SL[j * FPW + f] = lg2[v];
+      any |= v;
+    }
+    const unsigned long long smask = dbg_stop == 1 ? 0ull : __ballot(any != 0 && f < frames);
+    const bool mine = (smask >> lane) & 1ull;
+    if (f < frames && !mine) {  // a codeword: done (cyclic.h:225-231)
+      if (nerr_out) nerr_out[first + f] = 0;
+      if (status_out) status_out[first + f] = CC_FRAME_OK;
+    }
+    if (lane == 0) mask[chunk] = smask;
+    if (smask == 0) continue;  // wave-uniform
+
+    // Berlekamp-Massey, one lane per frame (hard_decision.h:116-155)
+    for (int m = 0; m < nc; ++m) {  // lambda = b = 1
+      LV[m * FPW + f] = m == 0;
+      LL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
+      BL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
+    }
+    int l = 0, shift = 0;  // b is stored unshifted; b(x) x^shift is the polynomial of the recurrence
+    for (int i = 0; i < t2; ++i) {
+      shift += 1;  // b = b * x, :134
+      const int lw = static_cast<int>(wave_umax(mine ? static_cast<uint32_t>(l) : 0u));
+      uint32_t d = SV[i * FPW + f];
+      const int mm = i < lw ? i : lw;
+      // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of four adds zeros
+      for (int m0 = 1; m0 <= mm; m0 += 4) {
+        uint32_t la[4], sa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u < nc ? m0 + u : nc - 1;
+          la[u] = LL[m * FPW + f];
+          sa[u] = SL[(i - m > 0 ? i - m : 0) * FPW + f];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d ^= ex[la[u] + sa[u]];
+      }
+      const bool upd = mine && d != 0;
+      const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
+      const uint32_t ld = lg2[d];
+      const uint32_t linv = static_cast<uint32_t>(nn) - ld;  // log of d^-1 (or nn for d = 1: wrapped below)
+      const int lnew = grow ? i + 1 - l : l;
+      const int cap = static_cast<int>(wave_umax(upd ? static_cast<uint32_t>(lnew) : 0u));
+      if (__any(upd)) {
+        // lambda += d * b * x^shift, and where the register grows b := lambda_old / d; descending m so that the
+        // shifted reads of the old b (index m - shift < m) happen before that index is overwritten
+        // four coefficients per trip, all reads before the look-ups before the writes: the stage is bound by the
+        // latency of its dependent LDS operations, and a read of b at m - shift always precedes the write of that
+        // index in the sequential order too
+        for (int m1 = cap; m1 >= 0; m1 -= 4) {
+          uint32_t lold[4], lv[4], bt[4], nv[4], ln[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = m1 - u > 0 ? m1 - u : 0, bi = m1 - u - shift;
+            lold[u] = LL[m * FPW + f];
+            lv[u] = LV[m * FPW + f];
+            bt[u] = bi >= 0 ? BL[(bi >= 0 ? bi : 0) * FPW + f] : kLogZero;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) nv[u] = lv[u] ^ ex[ld + bt[u]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ln[u] = lg2[nv[u]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = m1 - u;
+            if (m < 0) break;  // wave-uniform
+            if (upd) {
+              LV[m * FPW + f] = static_cast<uint8_t>(nv[u]);
+              LL[m * FPW + f] = static_cast<uint16_t>(ln[u]);
+            }
+            if (grow) {
+              uint32_t q = lold[u] + linv;
+              q = q >= static_cast<uint32_t>(nn) ? q - nn : q;
+              BL[m * FPW + f] = static_cast<uint16_t>(lold[u] >= kLogZero ? kLogZero : q);
+            }
+          }
+        }
+      }
+      if (grow) {
+        l = lnew;
+        shift = 0;
+      }
+    }
+    int deg = 0;
+    for (int m = t2; m >= 1; --m)
+      if (deg == 0 && LV[m * FPW + f] != 0) deg = m;
+    if (f < frames) meta[first + f] = static_cast<uint16_t>(deg | (l << 8));
+    for (int m = 0; m < nc; ++m) llg[(chunk * nc + m) * FPW + f] = LL[m * FPW + f];
+  }
+}
+
+// roots, error values, re-check and the patch of `out` (which already holds the received words), one dirty frame
+// of a 64-frame chunk at a time.  All polynomial arithmetic on logs with log 0 = 512 (no zero tests): a term
+// lambda_m X^-m is ex[log lambda_m + (m * log X^-1 mod nn)], the exponent advancing by one add + one wrap per
+// coefficient; wave-uniform coefficients come from a register by v_readlane, not from LDS.
+__global__ void __launch_bounds__(256)
+chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
+                 const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
+                 const unsigned long long *__restrict__ mask, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
+                 int32_t *__restrict__ status_out, unsigned long long B) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 4 * 320];
+  uint8_t *ex = smem;                                         // [1024]
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
+  uint8_t *lg = smem + 1536;                                  // [256] plain log table (log 0 = 0)
+  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+  const int dbg_stop = alg >> 8;
+  alg &= 0xFF;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n = T->n, nn = n, t2 = T->nroots, nc = t2 + 1;
+  const bool is_rs = T->family == CC_FAMILY_RS;
+  uint8_t *base = smem + 1792 + wid * 320;
+  uint16_t *CSL = reinterpret_cast<uint16_t *>(base);  // u16 [64] log S_j
+  uint8_t *CS = base + 128, *RP = base + 192, *VAL = base + 256;
+
+  const int r0 = T->roots_log[0];
+  const int step = t2 > 1 ? (T->roots_log[1] + nn - r0) % nn : 0;
+  uint32_t e0[4], dstep[4], xinv[4];
+  bool valid[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int p = lane + 64 * c;
+    valid[c] = p < n;
+    e0[c] = static_cast<uint32_t>((r0 * p) % nn);
+    dstep[c] = static_cast<uint32_t>((step * p) % nn);
+    xinv[c] = static_cast<uint32_t>((nn - (p % nn)) % nn);
+  }
+
+  const unsigned long long nchunks = (B + 63) / 64;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  const int jl = lane < t2 ? lane : t2 - 1, ml = lane < nc ? lane : nc - 1;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * 64;
+    unsigned long long todo = mask[chunk];
+    auto pop = [](unsigned long long &m) {
+      const int i = m ? __builtin_ctzll(m) : -1;
+      m &= m - 1;
+      return i;
+    };
+    auto fetch = [&](int f, uint32_t &sv, uint32_t &cll, uint32_t &md) {
+      const unsigned long long group = 2 * chunk + (f >> 5);
+      const int fi = f & 31;
+      sv = synd[((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3) + jl * 2048];
+      cll = llg[(chunk * nc + ml) * 64 + f];
+      md = meta[first + f];
+    };
+    int s0 = pop(todo);
+    uint32_t sv0 = 0, cll0 = 0, md0 = 0;
+    if (s0 >= 0) fetch(s0, sv0, cll0, md0);
+    while (s0 >= 0) {
+      const int s = s0;
+      const unsigned long long frame = first + s;
+      const uint32_t sv = sv0, cll = cll0;
+      const int deg = __builtin_amdgcn_readfirstlane(md0) & 0xFF, len = __builtin_amdgcn_readfirstlane(md0) >> 8;
+      s0 = pop(todo);
+      if (s0 >= 0) fetch(s0, sv0, cll0, md0);  // the next frame's operands travel while this one is worked on
+      uint32_t sym[4] = {0, 0, 0, 0}, corr[4] = {0, 0, 0, 0};
+      int status = CC_FRAME_OK, nerr = 0;
+      if (lane < t2) {
+        CS[lane] = static_cast<uint8_t>(sv);
+        CSL[lane] = lg2[sv];
+      }
+      // the PGZ tag runs as bounded-distance decoding: locator degree within capability
+      if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+      if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
+      if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
+
+      // root search: position p is in error iff lambda(alpha^-p) = 0  (cyclic.h:126-150)
+      uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
+      if (status == CC_FRAME_OK) {
+        uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
+#pragma unroll 2
+        for (int m = 0; m <= deg; ++m) {
+          const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc[c] ^= ex[lm + e[c]];
+            e[c] += xinv[c];
+            e[c] = umin32(e[c], e[c] - static_cast<uint32_t>(nn));
+          }
+        }
+        uint32_t count = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          isroot[c] = (valid[c] && acc[c] == 0) ? 1u : 0u;
+          const unsigned long long mk = __ballot(isroot[c] != 0);
+          rank[c] = count + static_cast<uint32_t>(__builtin_popcountll(mk & below));
+          count += static_cast<uint32_t>(__builtin_popcountll(mk));
+        }
+        nerr = static_cast<int>(count);
+        if (nerr != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
+        if (status == CC_FRAME_OK) {  // the symbols to patch: fetched now, needed after the error values
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (isroot[c]) sym[c] = out[frame * n + lane + 64 * c];
+        }
+      }
+      if (dbg_stop == 3) status = CC_FRAME_LOCATOR;
+
+      // error values: bch.h:80-83 (all ones) / Forney for rs.h:41-78, one lane per located error
+      if (status == CC_FRAME_OK && is_rs) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (isroot[c]) RP[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
+        uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg
+#pragma unroll 2
+        for (int m = 0; m <= deg; ++m) {
+          const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
+          const bool in = lane >= m && lane < deg && lane - m < t2;
+          om ^= in ? ex[lm + CSL[in ? lane - m : 0]] : 0u;
+        }
+        const uint32_t oml = lg2[om];
+        uint32_t y = 0;
+        if (lane < deg) {
+          const uint32_t p = RP[lane];
+          const uint32_t xi = p ? static_cast<uint32_t>(nn) - p : 0u;  // log X^-1
+          uint32_t x2 = 2 * xi;
+          x2 = umin32(x2, x2 - static_cast<uint32_t>(nn));
+          uint32_t num = 0, den = 0, e = 0;
+#pragma unroll 2
+          for (int j = 0; j < deg; ++j) {  // omega(X^-1)
+            num ^= ex[__builtin_amdgcn_readlane(oml, j) + e];
+            e += xi;
+            e = umin32(e, e - static_cast<uint32_t>(nn));
+          }
+          e = 0;
+#pragma unroll 2
+          for (int m = 1; m <= deg; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+            den ^= ex[__builtin_amdgcn_readlane(cll, m) + e];
+            e += x2;
+            e = umin32(e, e - static_cast<uint32_t>(nn));
+          }
+          y = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
+        }
+        VAL[lane] = static_cast<uint8_t>(y);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) corr[c] = isroot[c] ? VAL[rank[c]] : 0u;
+      } else if (status == CC_FRAME_OK) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) corr[c] = isroot[c];
+      }
+      // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip), evaluated otherwise
+      if (status == CC_FRAME_OK && len != deg) {
+        uint32_t ly[4], ev[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ly[c] = lg[corr[c]];
+          ev[c] = e0[c];
+        }
+        uint32_t mismatch = 0;
+        for (int j0 = 0; j0 < t2; j0 += 4) {
+          uint32_t packed = 0, want = 0;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            uint32_t term = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              term ^= corr[c] ? ex[ly[c] + ev[c]] : 0u;
+              ev[c] += dstep[c];
+              ev[c] = ev[c] >= static_cast<uint32_t>(nn) ? ev[c] - nn : ev[c];
+            }
+            if (j0 + jj < t2) {
+              packed |= term << (8 * jj);
+              want |= static_cast<uint32_t>(CS[j0 + jj]) << (8 * jj);
+            }
+          }
+          mismatch |= lane63(wave_xor(packed)) ^ want;
+        }
+        if (mismatch != 0) status = CC_FRAME_RECHECK;
+      }
+      const bool ok = status == CC_FRAME_OK;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (ok && corr[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ corr[c]);
       if (lane == 0) {
         if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
         if (status_out) status_out[frame] = status;
@@ -475,40 +840,51 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
   return CC_OK;
 }
 
-// syndromes on bit planes (bitslice.hip), then the chunk kernel from stage B on
+// syndromes on bit planes (bitslice.hip), Berlekamp-Massey over chunks of 64 frames, then the dirty frames one by one
 static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
                                   int32_t *d_status, size_t B, hipStream_t stream) {
-  const int t2 = static_cast<int>(code->tab.roots.size());
-  const unsigned long long G = (B + 31) / 32;
-  const size_t plane_bytes = static_cast<size_t>(G) * code->tab.n * 32, synd_bytes = static_cast<size_t>(G) * t2 * 32;
+  const int t2 = static_cast<int>(code->tab.roots.size()), nc = t2 + 1;
+  const unsigned long long G = (B + 31) / 32, chunks = (B + 63) / 64;
+  const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;  // planes and syndromes are laid out in blocks of 64 groups
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  const size_t plane_bytes = G64 * code->tab.n * 32, synd_bytes = G64 * t2 * 32;
+  const size_t llg_bytes = up(static_cast<size_t>(chunks) * nc * 64 * 2), meta_bytes = up(static_cast<size_t>(chunks) * 64 * 2);
+  const size_t mask_bytes = up(static_cast<size_t>(chunks) * 8);
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + synd_bytes, stream));
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes, stream));
   uint8_t *d_synd = ws + plane_bytes;
+  uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);
+  uint16_t *d_meta = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_llg) + llg_bytes);
+  unsigned long long *d_mask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(d_meta) + meta_bytes);
   int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
   if (rc == CC_OK) {
-    constexpr int FPW = 32;
-    const size_t lds = 1792 + 4 * static_cast<size_t>(chunk_layout(t2, FPW).bytes);
-    const unsigned long long blocks_needed = (G + 3) / 4;
-    unsigned long long per_cu = (160 * 1024) / lds;
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
-    const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
     static const int dbg_stop = [] {
       const char *e = std::getenv("CC_AMD_ALG_STOP");
       return e ? std::atoi(e) : 0;
     }();
-    const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
-    const unsigned long long Bq = B;
+    const unsigned long long Bq = B, blocks_needed = (chunks + 3) / 4;
+    const size_t lds = 1536 + 4 * static_cast<size_t>(bm_layout(t2).bytes);
+    unsigned long long per_cu = (160 * 1024) / lds;
+    if (per_cu < 1) per_cu = 1;
+    unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
+    int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&algebraic_chunk_kernel<false, FPW, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e == hipSuccess)
-      hipLaunchKernelGGL((algebraic_chunk_kernel<false, FPW, true>), dim3(grid), dim3(256), lds, stream, code->d_alg, alg_arg,
-                         static_cast<const void *>(nullptr), d_out, d_nerr, d_status, Bq, d_synd, G);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) rc = hip_fail(e, "algebraic chunk kernel launch");
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chunk_bm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
+                         d_mask, d_nerr, d_status, Bq);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+      max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
+      grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
+      hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
+                         code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, d_mask, d_out, d_nerr, d_status, Bq);
+      e = hipGetLastError();
+    }
+    if (e != hipSuccess) rc = hip_fail(e, "algebraic chunk kernels launch");
   }
   (void)hipFreeAsync(ws, stream);
   return rc;

@@ -7,14 +7,17 @@
 // on average 25.8 XORs per Horner step for j = 1 .. 32 including the addition of the next symbol: 0.8
 // instructions per symbol-multiply instead of a logarithm add, a wrap, a table gather and an XOR per symbol.
 //
-//   bitslice_planes_kernel     bytes [frame][n] -> planes [p][group][8] (group = 32 frames), and the copy of the
-//                              received words into the output buffer (the corrector only patches the errors)
+//   bitslice_planes_kernel     bytes [frame][n] -> planes [block of 64 groups][p][group][8] (group = 32 frames;
+//                              2 KB per position and block, read by one wavefront at a time), and the copy of the
+//                              received words into the output buffer (the corrector only patches the errors);
+//                              wavefront = group, lane = four adjacent positions
 //   bitslice_syndrome_kernel   lane = group, wavefront w of a workgroup = syndromes 8w+1 .. 8w+8 of the same 64
-//                              groups; the result goes back to bytes as [j][group][32]
+//                              groups; the result goes back to bytes as [block][j][group][32]
 //
 // The byte <-> plane transposition is three butterfly stages on eight registers whose word k carries the
 // frames {k, 8+k, 16+k, 24+k} of the group, so no bit permutation is left over; the consumer
-// (algebraic_chunk_kernel<PRE>) reads syndrome j of frame 8i + k of group g at byte ((j G + g) 32 + 4k + i).
+// (algebraic_chunk_kernel<PRE>) reads syndrome j of frame 8i + k of group g = 64 gb + gl at byte
+// ((gb 2t + j) 64 + gl) 32 + 4k + i.
 //
 // Field: GF(2^8) with the default modular polynomial 0x11d (galois.h:18-20), consecutive roots alpha^1 .. alpha^2t
 // (mu = step = 1), n = 255.  Everything else stays on the table kernels.
@@ -77,7 +80,9 @@ __device__ __forceinline__ void butterfly(uint32_t (&w)[8]) {
   }
 }
 
-// One wavefront per group of 32 frames, lane = symbol position (n = 255: four passes).
+// One wavefront per group of 32 frames.  Lane l owns the four positions q .. q+3, q = min(4 l, n - 4): one (unaligned)
+// dword per frame and lane instead of four byte loads -- the byte form was bound by the rate of the memory
+// instructions, 64 B each.  The last lane re-does position n - 4 .. 4 l - 1 of its neighbour (same values).
 template <bool FLOAT_IN>
 __global__ void __launch_bounds__(256)
 bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ out, uint4 *__restrict__ planes,
@@ -85,39 +90,48 @@ bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ ou
   const int lane = threadIdx.x & 63;
   const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  const int q = 4 * lane < n - 4 ? 4 * lane : n - 4;
   for (unsigned long long g = wave; g < G; g += nwaves) {
     const unsigned long long f0 = g * 32;
     const int frames = static_cast<int>((B - f0) < 32ull ? (B - f0) : 32ull);
-    for (int p0 = 0; p0 < n; p0 += 64) {
-      const int p = p0 + lane;
-      if (p >= n) continue;
-      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      auto fetch = [&](int f) -> uint32_t {
-        const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n) + p;
-        if (FLOAT_IN)  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
-          return static_cast<const float *>(in_raw)[at] < 0.0f ? 1u : 0u;
-        return static_cast<const uint8_t *>(in_raw)[at];
-      };
-      if (frames == 32) {
-        uint32_t v[32];
+    uint32_t v[32];
+    auto fetch = [&](int f) -> uint32_t {
+      const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n) + q;
+      if (FLOAT_IN) {  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
+        const float *x = static_cast<const float *>(in_raw) + at;
+        return (x[0] < 0.0f ? 1u : 0u) | (x[1] < 0.0f ? 0x100u : 0u) | (x[2] < 0.0f ? 0x10000u : 0u) |
+               (x[3] < 0.0f ? 0x1000000u : 0u);
+      }
+      uint32_t r;
+      __builtin_memcpy(&r, static_cast<const uint8_t *>(in_raw) + at, 4);
+      return r;
+    };
+    if (frames == 32) {
 #pragma unroll
-        for (int f = 0; f < 32; ++f) v[f] = fetch(f);
+      for (int f = 0; f < 32; ++f) v[f] = fetch(f);
 #pragma unroll
-        for (int f = 0; f < 32; ++f) {
-          out[(f0 + f) * static_cast<unsigned long long>(n) + p] = static_cast<uint8_t>(v[f]);
-          w[f & 7] |= v[f] << (8 * (f >> 3));
-        }
-      } else {
-        for (int f = 0; f < frames; ++f) {
-          const uint32_t v = fetch(f);
-          out[(f0 + f) * static_cast<unsigned long long>(n) + p] = static_cast<uint8_t>(v);
+      for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+    } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if ((f & 7) == k) w[k] |= v << (8 * (f >> 3));
+      for (int f = 0; f < 32; ++f) {
+        v[f] = 0;
+        if (f < frames) {
+          v[f] = fetch(f);
+          __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
         }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // word k = byte i of the frames {k, 8+k, 16+k, 24+k}
+        const uint32_t sel = 0x0c0c0000u | static_cast<uint32_t>((4 + i) << 8) | static_cast<uint32_t>(i);
+        const uint32_t lo = __builtin_amdgcn_perm(v[8 + k], v[k], sel), hi = __builtin_amdgcn_perm(v[24 + k], v[16 + k], sel);
+        w[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
       butterfly(w);  // word b, bit f = bit b of the symbol of frame f
-      uint4 *dst = planes + (static_cast<unsigned long long>(p) * G + g) * 2;
+      uint4 *dst = planes + (((g >> 6) * n + (q + i)) * 64 + (g & 63)) * 2;
       dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
@@ -132,8 +146,8 @@ __device__ __forceinline__ void syndromes8(const uint4 *__restrict__ planes, uin
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int b = 0; b < 8; ++b) s[j][b] = 0;
-  const uint4 *src = planes + g * 2;
-  const unsigned long long pitch = G * 2;
+  const uint4 *src = planes + ((g >> 6) * n * 64 + (g & 63)) * 2;
+  const unsigned long long pitch = 128;
   auto all8 = [&](const uint32_t (&r)[8]) {
     horner<J0 + 1>(s[0], r);
     horner<J0 + 2>(s[1], r);
@@ -171,7 +185,7 @@ __device__ __forceinline__ void syndromes8(const uint4 *__restrict__ planes, uin
   for (int j = 0; j < 8; ++j) {
     if (J0 + j >= t2) break;
     butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
-    uint4 *dst = reinterpret_cast<uint4 *>(synd + (static_cast<unsigned long long>(J0 + j) * G + g) * 32);
+    uint4 *dst = reinterpret_cast<uint4 *>(synd + (((g >> 6) * t2 + (J0 + j)) * 64 + (g & 63)) * 32);
     dst[0] = make_uint4(s[j][0], s[j][1], s[j][2], s[j][3]);
     dst[1] = make_uint4(s[j][4], s[j][5], s[j][6], s[j][7]);
   }
@@ -207,7 +221,7 @@ bool bitslice_supported(const cc_code *code) {
   return true;
 }
 
-// planes: G * n * 32 bytes, synd: t2 * G * 32 bytes, G = ceil(B / 32)
+// planes: G64 * n * 32 bytes, synd: G64 * t2 * 32 bytes, G64 = ceil(B / 2048) * 64 groups of 32 frames
 int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, void *d_planes,
                               uint8_t *d_synd, size_t B, hipStream_t stream) {
   const int n = static_cast<int>(code->tab.n), t2 = static_cast<int>(code->tab.roots.size());
