@@ -476,7 +476,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
   lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
   __syncthreads();
   constexpr int FPW = 64;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, f = lane;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = lane;
   const int nn = T->n, t2 = T->nroots, nc = t2 + 1;
   const BmLayout lay = bm_layout(t2);
   uint8_t *base = smem + 1536 + wid * lay.bytes;
@@ -609,7 +609,7 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
   __syncthreads();
   const int dbg_stop = alg >> 8;
   alg &= 0xFF;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = T->n, nn = n, t2 = T->nroots, nc = t2 + 1;
   const bool is_rs = T->family == CC_FAMILY_RS;
   uint8_t *base = smem + 1792 + wid * 320;

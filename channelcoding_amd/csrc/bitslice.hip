@@ -86,17 +86,22 @@ __device__ __forceinline__ void butterfly(uint32_t (&w)[8]) {
 template <bool FLOAT_IN>
 __global__ void __launch_bounds__(256)
 bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ out, uint4 *__restrict__ planes,
-                       unsigned long long B, unsigned long long G, int n) {
+                       unsigned long long B, unsigned long long G, int n_in, int n, int off) {
   const int lane = threadIdx.x & 63;
-  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  // (made wave-uniform for the compiler: frame addresses become scalar bases plus one 32-bit lane offset)
+  const unsigned long long wave =
+      static_cast<unsigned long long>(blockIdx.x) * 4 + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
   const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
-  const int q = 4 * lane < n - 4 ? 4 * lane : n - 4;
+  // decoding: n_in = n, off = 0.  Encoding: the n_in message symbols of a frame go to the positions off .. n - 1 of
+  // its codeword (cyclic.h:29-40) and of the planes; the parity positions below off are filled in later.
+  if (4 * lane >= n_in + 3) return;
+  const int q = 4 * lane < n_in - 4 ? 4 * lane : n_in - 4;
   for (unsigned long long g = wave; g < G; g += nwaves) {
     const unsigned long long f0 = g * 32;
     const int frames = static_cast<int>((B - f0) < 32ull ? (B - f0) : 32ull);
     uint32_t v[32];
     auto fetch = [&](int f) -> uint32_t {
-      const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n) + q;
+      const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n_in) + q;
       if (FLOAT_IN) {  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
         const float *x = static_cast<const float *>(in_raw) + at;
         return (x[0] < 0.0f ? 1u : 0u) | (x[1] < 0.0f ? 0x100u : 0u) | (x[2] < 0.0f ? 0x10000u : 0u) |
@@ -110,14 +115,14 @@ bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ ou
 #pragma unroll
       for (int f = 0; f < 32; ++f) v[f] = fetch(f);
 #pragma unroll
-      for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+      for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
     } else {
 #pragma unroll
       for (int f = 0; f < 32; ++f) {
         v[f] = 0;
         if (f < frames) {
           v[f] = fetch(f);
-          __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+          __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
         }
       }
     }
@@ -131,16 +136,18 @@ bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ ou
         w[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
       butterfly(w);  // word b, bit f = bit b of the symbol of frame f
-      uint4 *dst = planes + (((g >> 6) * n + (q + i)) * 64 + (g & 63)) * 2;
+      uint4 *dst = planes + (((g >> 6) * n + (off + q + i)) * 64 + (g & 63)) * 2;
       dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
 }
 
-template <int J0>  // syndromes of the roots alpha^(J0+1) .. alpha^(J0+8)
+// syndromes of the roots alpha^(J0+1) .. alpha^(J0+8).  Positions below p_lo count as zero (the parity positions of
+// a word that is being encoded); RAW keeps the result on planes ([block][j][group][8]) for the interpolation.
+template <int J0, bool RAW>
 __device__ __forceinline__ void syndromes8(const uint4 *__restrict__ planes, uint8_t *__restrict__ synd,
-                                           unsigned long long G, unsigned long long g, int n, int t2) {
+                                           unsigned long long g, int n, int t2, int p_lo) {
   uint32_t s[8][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -162,45 +169,190 @@ __device__ __forceinline__ void syndromes8(const uint4 *__restrict__ planes, uin
   // update needs no register copies
   int p = n - 1;
   uint4 a0 = src[static_cast<unsigned long long>(p) * pitch], b0 = src[static_cast<unsigned long long>(p) * pitch + 1];
-  if ((n & 1) != 0) {
+  if (((n - p_lo) & 1) != 0) {
     const uint32_t r[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
     all8(r);
     --p;
-    if (p >= 0) {
+    if (p >= p_lo) {
       a0 = src[static_cast<unsigned long long>(p) * pitch];
       b0 = src[static_cast<unsigned long long>(p) * pitch + 1];
     }
   }
-  for (; p >= 1; p -= 2) {
+  for (; p >= p_lo + 1; p -= 2) {
     const uint4 a1 = src[static_cast<unsigned long long>(p - 1) * pitch], b1 = src[static_cast<unsigned long long>(p - 1) * pitch + 1];
     const uint32_t r0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
     const uint32_t r1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
-    const int pn = p >= 2 ? p - 2 : 0;  // the last trip re-reads position 0 (no branch around the prefetch)
+    const int pn = p >= p_lo + 2 ? p - 2 : p_lo;  // the last trip re-reads a position (no branch around the prefetch)
     a0 = src[static_cast<unsigned long long>(pn) * pitch];
     b0 = src[static_cast<unsigned long long>(pn) * pitch + 1];
     all8(r0);
     all8(r1);
   }
+  if (RAW) {
+    const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < p_lo; z += 2) {  // times x^p_lo (p_lo is even)
+      all8(zero);
+      all8(zero);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (J0 + j >= t2) break;
-    butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
+    if (!RAW) butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
     uint4 *dst = reinterpret_cast<uint4 *>(synd + (((g >> 6) * t2 + (J0 + j)) * 64 + (g & 63)) * 32);
     dst[0] = make_uint4(s[j][0], s[j][1], s[j][2], s[j][3]);
     dst[1] = make_uint4(s[j][4], s[j][5], s[j][6], s[j][7]);
   }
 }
 
+template <bool RAW>
 __global__ void __launch_bounds__(256)
-bitslice_syndrome_kernel(const uint4 *__restrict__ planes, uint8_t *__restrict__ synd, unsigned long long G, int n, int t2) {
+bitslice_syndrome_kernel(const uint4 *__restrict__ planes, uint8_t *__restrict__ synd, unsigned long long G, int n, int t2,
+                         int p_lo) {
   const int wid = threadIdx.x >> 6;
   const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * 64 + (threadIdx.x & 63);
   if (g >= G) return;
   switch (wid) {
-    case 0: syndromes8<0>(planes, synd, G, g, n, t2); break;
-    case 1: syndromes8<8>(planes, synd, G, g, n, t2); break;
-    case 2: syndromes8<16>(planes, synd, G, g, n, t2); break;
-    default: syndromes8<24>(planes, synd, G, g, n, t2); break;
+    case 0: syndromes8<0, RAW>(planes, synd, g, n, t2, p_lo); break;
+    case 1: syndromes8<8, RAW>(planes, synd, g, n, t2, p_lo); break;
+    case 2: syndromes8<16, RAW>(planes, synd, g, n, t2, p_lo); break;
+    default: syndromes8<24, RAW>(planes, synd, g, n, t2, p_lo); break;
+  }
+}
+
+// ---------------- systematic encoding by evaluation and interpolation ----------------
+// c(x) = a(x) x^k + r(x), deg r < k = 2t, and c(alpha^j) = 0 for j = 1 .. 2t: with E_j = (a x^k)(alpha^j) from the
+// Horner kernel above, r is the polynomial with r(alpha^j) = E_j, i.e. r_i = sum_j W[i][j] E_j with W the inverse of
+// the Vandermonde matrix V[j][i] = alpha^(j i) -- k^2 multiplications by constants per frame instead of k (n - k),
+// and constants are XOR networks on the planes.  Same codeword as the division (the remainder is unique).
+struct Gf256 {
+  uint8_t exp[512], log[256];
+  constexpr Gf256() : exp{}, log{} {
+    uint32_t v = 1;
+    for (int i = 0; i < 255; ++i) {
+      exp[i] = static_cast<uint8_t>(v);
+      exp[i + 255] = static_cast<uint8_t>(v);
+      log[v] = static_cast<uint8_t>(i);
+      v = times_alpha(v);
+    }
+  }
+  constexpr uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+  constexpr uint8_t inv(uint8_t a) const { return exp[255 - log[a]]; }
+};
+template <int K> struct InverseVandermonde {
+  uint8_t w[K][K];
+  constexpr InverseVandermonde() : w{} {
+    Gf256 f;
+    uint8_t v[K][K] = {};
+    for (int j = 0; j < K; ++j)
+      for (int i = 0; i < K; ++i) {
+        v[j][i] = f.exp[((j + 1) * i) % 255];
+        w[j][i] = i == j;
+      }
+    for (int c = 0; c < K; ++c) {  // Gauss-Jordan (V is invertible: distinct evaluation points)
+      int piv = c;
+      while (v[piv][c] == 0) ++piv;
+      for (int i = 0; i < K; ++i) {
+        const uint8_t t0 = v[c][i], t1 = w[c][i];
+        v[c][i] = v[piv][i];
+        v[piv][i] = t0;
+        w[c][i] = w[piv][i];
+        w[piv][i] = t1;
+      }
+      const uint8_t s = f.inv(v[c][c]);
+      for (int i = 0; i < K; ++i) {
+        v[c][i] = f.mul(v[c][i], s);
+        w[c][i] = f.mul(w[c][i], s);
+      }
+      for (int r = 0; r < K; ++r) {
+        if (r == c || v[r][c] == 0) continue;
+        const uint8_t m = v[r][c];
+        for (int i = 0; i < K; ++i) {
+          v[r][i] ^= f.mul(m, v[c][i]);
+          w[r][i] ^= f.mul(m, w[c][i]);
+        }
+      }
+    }
+  }
+};
+template <int K> inline constexpr InverseVandermonde<K> kInvV{};
+
+constexpr uint32_t times_const(uint32_t c, uint32_t v) {  // c * v in GF(2^8)
+  uint32_t r = 0;
+  for (int i = 0; i < 8; ++i) {
+    if ((v >> i) & 1u) r ^= c;
+    c = times_alpha(c);
+  }
+  return r;
+}
+// acc += C * e on 32 frames (C a compile-time constant: the taps fold to a fixed XOR network)
+template <int C> __device__ __forceinline__ void mac(uint32_t (&acc)[8], const uint32_t (&e)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if ((times_const(C, 1u << c) >> b) & 1u) acc[b] ^= e[c];
+}
+template <int K, int I0, int J, int... I>
+__device__ __forceinline__ void interp_column(uint32_t (&acc)[8][8], const uint32_t (&e)[8], std::integer_sequence<int, I...>) {
+  (mac<kInvV<K>.w[I0 + I][J]>(acc[I], e), ...);
+}
+template <int K, int I0, int J>
+__device__ __forceinline__ void interp_one(uint32_t (&acc)[8][8], const uint4 *__restrict__ ev) {
+  const uint4 a = ev[static_cast<unsigned long long>(J) * 128], b = ev[static_cast<unsigned long long>(J) * 128 + 1];
+  const uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  interp_column<K, I0, J>(acc, e, std::make_integer_sequence<int, 8>());
+}
+template <int K, int I0, int... J>
+__device__ __forceinline__ void interp_all(uint32_t (&acc)[8][8], const uint4 *__restrict__ ev, std::integer_sequence<int, J...>) {
+  (interp_one<K, I0, J>(acc, ev), ...);
+}
+// parity symbols I0 .. I0+7 of the 32 frames of group g -> cw[frame][I0 .. I0+7]
+template <int K, int I0>
+__device__ __forceinline__ void parity8(const uint4 *__restrict__ evals, uint8_t *__restrict__ cw, unsigned long long g,
+                                        unsigned long long B, int n) {
+  uint32_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[i][b] = 0;
+  interp_all<K, I0>(acc, evals + ((g >> 6) * K * 64 + (g & 63)) * 2, std::make_integer_sequence<int, K>());
+#pragma unroll
+  for (int i = 0; i < 8; ++i) butterfly(acc[i]);  // word k of symbol i = its bytes for the frames {k, 8+k, 16+k, 24+k}
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned long long frame = g * 32 + 8 * h + k;
+      if (frame >= B) continue;
+      const uint32_t sel = 0x0c0c0000u | static_cast<uint32_t>((4 + h) << 8) | static_cast<uint32_t>(h);
+      uint32_t w[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // byte h of the words k of four adjacent symbols
+        const uint32_t lo = __builtin_amdgcn_perm(acc[4 * half + 1][k], acc[4 * half][k], sel);
+        const uint32_t hi = __builtin_amdgcn_perm(acc[4 * half + 3][k], acc[4 * half + 2][k], sel);
+        w[half] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+      }
+      __builtin_memcpy(cw + frame * static_cast<unsigned long long>(n) + I0, w, 8);
+    }
+}
+template <int K>
+__global__ void __launch_bounds__(256)
+bitslice_parity_kernel(const uint4 *__restrict__ evals, uint8_t *__restrict__ cw, unsigned long long B, unsigned long long G,
+                       int n) {
+  const int wid = threadIdx.x >> 6;
+  const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * 64 + (threadIdx.x & 63);
+  if (g >= G) return;
+  if constexpr (K == 32) {
+    switch (wid) {
+      case 0: parity8<K, 0>(evals, cw, g, B, n); break;
+      case 1: parity8<K, 8>(evals, cw, g, B, n); break;
+      case 2: parity8<K, 16>(evals, cw, g, B, n); break;
+      default: parity8<K, 24>(evals, cw, g, B, n); break;
+    }
+  } else {
+    if (wid == 0) parity8<K, 0>(evals, cw, g, B, n);
+    else parity8<K, 8>(evals, cw, g, B, n);
   }
 }
 
@@ -230,17 +382,57 @@ int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_
   const int grid = static_cast<int>(want < cap ? want : cap);
   if (float_in)
     hipLaunchKernelGGL((bitslice_planes_kernel<true>), dim3(grid), dim3(256), 0, stream, d_in, d_out,
-                       static_cast<uint4 *>(d_planes), Bq, G, n);
+                       static_cast<uint4 *>(d_planes), Bq, G, n, n, 0);
   else
     hipLaunchKernelGGL((bitslice_planes_kernel<false>), dim3(grid), dim3(256), 0, stream, d_in, d_out,
-                       static_cast<uint4 *>(d_planes), Bq, G, n);
+                       static_cast<uint4 *>(d_planes), Bq, G, n, n, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice planes kernel launch");
   const int waves = (t2 + 7) / 8;
-  hipLaunchKernelGGL(bitslice_syndrome_kernel, dim3(static_cast<unsigned>((G + 63) / 64)), dim3(64 * waves), 0, stream,
-                     static_cast<const uint4 *>(d_planes), d_synd, G, n, t2);
+  hipLaunchKernelGGL((bitslice_syndrome_kernel<false>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(64 * waves), 0,
+                     stream, static_cast<const uint4 *>(d_planes), d_synd, G, n, t2, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice syndrome kernel launch");
+  return CC_OK;
+}
+
+bool bitslice_encode_supported(const cc_code *code) {
+  if (!bitslice_supported(code) || code->desc.coding != CC_CODING_DIVISION) return false;
+  const size_t k = code->tab.roots.size();  // the generator is the product of the (x - root_j): k = 2t parity symbols
+  return code->tab.family == CC_FAMILY_RS && code->tab.k == k && (k == 16 || k == 32);
+}
+
+// systematic encoder (cyclic.h:29-40, division_tag) on bit planes: message -> planes and codeword body, evaluations
+// at the 2t roots, interpolation of the remainder
+int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream) {
+  const int n = static_cast<int>(code->tab.n), k = static_cast<int>(code->tab.k), l = static_cast<int>(code->tab.l);
+  const unsigned long long G = (B + 31) / 32, Bq = B;
+  const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;
+  const size_t plane_bytes = G64 * n * 32, eval_bytes = G64 * k * 32;
+  uint8_t *ws = nullptr;  // stream-ordered and pool-cached
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + eval_bytes, stream));
+  uint8_t *d_eval = ws + plane_bytes;
+  const unsigned long long want = (G + 3) / 4, cap = static_cast<unsigned long long>(code->num_cus) * 32;
+  const int grid = static_cast<int>(want < cap ? want : cap);
+  hipLaunchKernelGGL((bitslice_planes_kernel<false>), dim3(grid), dim3(256), 0, stream, static_cast<const void *>(d_msg), d_cw,
+                     reinterpret_cast<uint4 *>(ws), Bq, G, l, n, k);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((bitslice_syndrome_kernel<true>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(64 * (k / 8)), 0,
+                       stream, reinterpret_cast<const uint4 *>(ws), d_eval, G, n, k, k);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    if (k == 32)
+      hipLaunchKernelGGL((bitslice_parity_kernel<32>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(256), 0, stream,
+                         reinterpret_cast<const uint4 *>(d_eval), d_cw, Bq, G, n);
+    else
+      hipLaunchKernelGGL((bitslice_parity_kernel<16>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(128), 0, stream,
+                         reinterpret_cast<const uint4 *>(d_eval), d_cw, Bq, G, n);
+    e = hipGetLastError();
+  }
+  (void)hipFreeAsync(ws, stream);
+  if (e != hipSuccess) return hip_fail(e, "bitslice encode kernels launch");
   return CC_OK;
 }
 

@@ -269,6 +269,7 @@ std::vector<uint8_t> build_parity_table(const Field &f, const CodeTables &t) {
 
 int launch_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream) {
   if (B == 0) return CC_OK;
+  if (bitslice_encode_supported(code)) return launch_bitslice_encode(code, d_msg, d_cw, B, stream);
   const unsigned long long blocks_needed = (B + 3) / 4;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
