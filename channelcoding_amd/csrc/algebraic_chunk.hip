@@ -51,14 +51,11 @@ __host__ __device__ inline ChunkLayout chunk_layout(int t2, int fpw) {
   return c;
 }
 
-// PRE: the syndromes come from bitslice.hip ([j][group of 32 frames][32], FPW == 32) and `out` already holds the
-// received words: stage A only fetches them, stage C only patches the located errors.
-template <bool FLOAT_IN, int FPW, bool PRE = false>
+template <bool FLOAT_IN, int FPW>
 __global__ void __launch_bounds__(256, 4)
 algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__restrict__ in_raw,
                        uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
-                       unsigned long long B, const uint8_t *__restrict__ synd = nullptr, unsigned long long G = 0) {
-  static_assert(!PRE || FPW == 32, "a chunk is one group of the bit-plane layout");
+                       unsigned long long B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t *ex = smem;                                            // [1024]
   uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);     // [256]
@@ -81,7 +78,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
   uint8_t *SV = base + lay.SV, *LV = base + lay.LV, *DEG = base + lay.DEG, *LEN = base + lay.LEN;
   uint16_t *CSL = reinterpret_cast<uint16_t *>(base + lay.CSL);
   uint16_t *CLL = reinterpret_cast<uint16_t *>(base + lay.CLL);
-  uint16_t *OML = reinterpret_cast<uint16_t *>(base + lay.OML);
   uint8_t *CS = base + lay.CS, *RP = base + lay.RP, *VAL = base + lay.VAL;
 
   // per-lane exponent bookkeeping (roots alpha^(r0 + j step)): position p = lane + 64 c
@@ -126,25 +122,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
     // constants, so a term costs one add, one table read and one XOR.  A zero symbol parks lt on the zero
     // part of the table (log 0 = 512) and advances by nn, which the wrap undoes.
     unsigned long long smask = 0;  // frames with a non-zero syndrome
-    if (PRE) {
-      const int f = lane & 31;
-      // [block of 64 groups][j][group in block][32]; frame 8i + k of the group: byte 4k + i
-      const uint8_t *src = synd + ((chunk >> 6) * t2 * 64 + (chunk & 63)) * 32 + 4 * (f & 7) + (f >> 3);
-      uint32_t any = 0;
-#pragma unroll 4
-      for (int j = lane >> 5; j < t2; j += 2) {
-        const uint32_t v = src[j * 2048];
-        SV[j * FPW + f] = static_cast<uint8_t>(v);
-        SL[j * FPW + f] = lg2[v];
-        any |= v;
-      }
-      const unsigned long long m = __ballot(any != 0 && f < frames);
-      smask = dbg_stop == 1 ? 0ull : ((m | (m >> 32)) & 0xFFFFFFFFull);
-      if (lane < frames && !((smask >> lane) & 1ull)) {  // a codeword: done (cyclic.h:225-231)
-        if (nerr_out) nerr_out[first + lane] = 0;
-        if (status_out) status_out[first + lane] = CC_FRAME_OK;
-      }
-    } else {
     constexpr int PF = 3;          // frames in flight: the stage is latency-bound otherwise (255 B per frame)
     uint32_t symq[PF][4];
 #pragma unroll
@@ -205,7 +182,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           }
         }
       }
-    }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -292,8 +268,8 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
     unsigned long long todo = smask;
     int s0 = pop(todo), s1 = pop(todo);
     uint32_t q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
-    if (!PRE && s0 >= 0) load_symbols(first + s0, q0);
-    if (!PRE && s1 >= 0) load_symbols(first + s1, q1);
+    if (s0 >= 0) load_symbols(first + s0, q0);
+    if (s1 >= 0) load_symbols(first + s1, q1);
     while (s0 >= 0) {
       const int s = s0;
       const unsigned long long frame = first + s;
@@ -305,7 +281,7 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
       }
       s0 = s1;
       s1 = pop(todo);
-      if (!PRE && s1 >= 0) load_symbols(first + s1, q1);
+      if (s1 >= 0) load_symbols(first + s1, q1);
       int status = CC_FRAME_OK, nerr = 0;
       {
         const int deg = DEG[s], len = LEN[s];
@@ -346,11 +322,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           }
           nerr = static_cast<int>(count);
           if (nerr != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
-          if (PRE && status == CC_FRAME_OK) {  // the symbols to patch: fetched now, needed after the error values
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (isroot[c]) sym[c] = out[frame * n + lane + 64 * c];
-          }
         }
         if (dbg_stop == 3) status = CC_FRAME_LOCATOR;
 
@@ -428,13 +399,8 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
       }
       const bool ok = status == CC_FRAME_OK;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (PRE) {
-          if (ok && corr[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ corr[c]);
-        } else if (valid[c]) {
-          out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
-        }
-      }
+      for (int c = 0; c < 4; ++c)
+        if (valid[c]) out[frame * n + lane + 64 * c] = static_cast<uint8_t>(sym[c] ^ (ok ? corr[c] : 0u));
       if (lane == 0) {
         if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
         if (status_out) status_out[frame] = status;

@@ -1057,8 +1057,13 @@ int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames
   if (code->soft) {
     minsum_kernel_info(code, nm, f, t, l);
   } else if (algebraic_chunk_supported(code, false)) {
-    nm = "algebraic_chunk_kernel<FPW=32> (algebraic_kernel with erasures)";
-    f = 128;
+    if (bitslice_supported(code)) {
+      nm = "algebraic_chunk_kernel, split: bitslice_syndrome_kernel + chunk_bm_kernel + chunk_fix_kernel (algebraic_kernel with erasures)";
+      f = 256;
+    } else {
+      nm = "algebraic_chunk_kernel<FPW=32> (algebraic_kernel with erasures)";
+      f = 128;
+    }
   }
   if (name && cap) std::snprintf(name, cap, "%s", nm.c_str());
   if (frames_per_workgroup) *frames_per_workgroup = f;

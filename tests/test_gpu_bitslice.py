@@ -1,0 +1,84 @@
+"""GPU parity tests of the bit-plane path of GF(2^8) codes (csrc/bitslice.hip + the split chunk kernels): syndromes
+as XOR networks on 32 frames per register, Berlekamp-Massey over 64-frame chunks, the correction kernel, and the
+encoder by evaluation + interpolation.  Against the plain-C oracle, bit-exact, at batch sizes around every layout
+boundary (32 frames per group, 64 per chunk, 2048 per block)."""
+import numpy as np
+import pytest
+
+from checkers import BCH, BM, PGZ, RS, Oracle
+from test_gpu_algebraic import TAGS, check_against_oracle, corrupt
+
+import channelcoding_amd as cc
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (1, 31, 32, 33, 63, 64, 65, 700, 2047, 2048, 2049, 4161)
+
+
+def make(fam, t, alg=BM):
+    return (cc.primitive_bch if fam == BCH else cc.rs)(8, cc.errors(t), TAGS[alg]())
+
+
+@pytest.mark.parametrize("fam,t", [(RS, 16), (RS, 8), (RS, 4), (RS, 5), (BCH, 4), (BCH, 9)])
+def test_decode_at_layout_boundaries(fam, t):
+    o = Oracle(fam, 8, t)
+    code = make(fam, t)
+    assert code.kernel_info()["kernel"].startswith("algebraic_chunk_kernel")
+    rng = np.random.default_rng(1000 * fam + t)
+    hi = 2 if fam == BCH else 256
+    for frames in SIZES:
+        if frames > 700 and t not in (16, 4):
+            continue
+        cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+        rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, o.t + 3))) for f in range(frames)])
+        rx[frames // 2] = cw[frames // 2]  # a clean frame among dirty ones
+        check_against_oracle(code.correct_batch(rx), o, BM, rx)
+
+
+def test_pgz_tag_and_signed_input():
+    """The PGZ tag (bounded-distance) and float input (bit = x < 0, cyclic.h:163-173) through the same kernels."""
+    o = Oracle(BCH, 8, 6)
+    rng = np.random.default_rng(77)
+    frames = 2100
+    cw = o.encode(rng.integers(0, 2, (frames, o.l)).astype(np.uint8))
+    rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, o.t + 3))) for f in range(frames)])
+    soft = np.where(rx != 0, -1.0, 1.0).astype(np.float32) * rng.uniform(0.1, 3.0, rx.shape).astype(np.float32)
+    for alg in (BM, PGZ):
+        code = make(BCH, 6, alg)
+        a = code.correct_batch(rx)
+        b = code.correct_batch(soft)
+        for key in ("out", "status", "nerr"):
+            assert np.array_equal(a[key], b[key]), key
+        check_against_oracle(a, o, alg, rx)
+
+
+def test_all_clean_and_all_dirty_chunks():
+    o = Oracle(RS, 8, 16)
+    code = make(RS, 16)
+    rng = np.random.default_rng(5)
+    cw = o.encode(rng.integers(0, 256, (256, o.l)).astype(np.uint8))
+    res = code.correct_batch(cw)
+    assert (res["status"] == 0).all() and (res["nerr"] == 0).all() and np.array_equal(res["out"], cw)
+    rx = np.stack([corrupt(rng, o, cw[f], 16) for f in range(256)])
+    res = code.correct_batch(rx)
+    assert (res["status"] == 0).all() and (res["nerr"] == 16).all() and np.array_equal(res["out"], cw)
+    rx = np.stack([corrupt(rng, o, cw[f], 40) for f in range(256)])  # far beyond the capability
+    check_against_oracle(code.correct_batch(rx), o, BM, rx)
+
+
+@pytest.mark.parametrize("t", [16, 8])
+def test_encode_by_interpolation(t):
+    """RS(255,223) / RS(255,239): the remainder of the division, computed as the interpolation of the evaluations at
+    the 2t roots, equals the oracle's long division; extraction returns the message."""
+    o = Oracle(RS, 8, t)
+    code = make(RS, t)
+    rng = np.random.default_rng(300 + t)
+    for frames in SIZES:
+        msg = rng.integers(0, 256, (frames, o.l)).astype(np.uint8)
+        msg[0] = 0
+        if frames > 2:
+            msg[1] = 255
+            msg[2, :-1] = 0  # a single non-zero symbol at the top position
+        cw = code.encode_batch(msg)
+        assert np.array_equal(cw, o.encode(msg)), frames
+        assert np.array_equal(code.extract_batch(cw), msg)
