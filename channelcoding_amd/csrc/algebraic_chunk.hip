@@ -565,10 +565,15 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                  const unsigned long long *__restrict__ mask, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
                  int32_t *__restrict__ status_out, unsigned long long B) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 4 * 320];
+  // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
+  // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
+  constexpr uint32_t kLongZero = 8448, kLongSize = 16640;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 4 * 320 + kLongSize];
   uint8_t *ex = smem;                                         // [1024]
   uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
   uint8_t *lg = smem + 1536;                                  // [256] plain log table (log 0 = 0)
+  uint8_t *exl = smem + 1792 + 4 * 320;
+  for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kLongZero ? T->exp[i % 255u] : 0;
   for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
   lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
   lg[threadIdx.x] = T->log[threadIdx.x];
@@ -639,14 +644,12 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
       uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
       if (status == CC_FRAME_OK) {
         uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
-#pragma unroll 2
         for (int m = 0; m <= deg; ++m) {
-          const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
+          const uint32_t l0 = __builtin_amdgcn_readlane(cll, m), lm = l0 >= kLogZero ? kLongZero : l0;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            acc[c] ^= ex[lm + e[c]];
+            acc[c] ^= exl[lm + e[c]];
             e[c] += xinv[c];
-            e[c] = umin32(e[c], e[c] - static_cast<uint32_t>(nn));
           }
         }
         uint32_t count = 0;
@@ -674,7 +677,6 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
         for (int c = 0; c < 4; ++c)
           if (isroot[c]) RP[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
         uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg
-#pragma unroll 2
         for (int m = 0; m <= deg; ++m) {
           const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
           const bool in = lane >= m && lane < deg && lane - m < t2;
@@ -688,18 +690,16 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
           uint32_t x2 = 2 * xi;
           x2 = umin32(x2, x2 - static_cast<uint32_t>(nn));
           uint32_t num = 0, den = 0, e = 0;
-#pragma unroll 2
           for (int j = 0; j < deg; ++j) {  // omega(X^-1)
-            num ^= ex[__builtin_amdgcn_readlane(oml, j) + e];
+            const uint32_t l0 = __builtin_amdgcn_readlane(oml, j);
+            num ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
             e += xi;
-            e = umin32(e, e - static_cast<uint32_t>(nn));
           }
           e = 0;
-#pragma unroll 2
           for (int m = 1; m <= deg; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
-            den ^= ex[__builtin_amdgcn_readlane(cll, m) + e];
+            const uint32_t l0 = __builtin_amdgcn_readlane(cll, m);
+            den ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
             e += x2;
-            e = umin32(e, e - static_cast<uint32_t>(nn));
           }
           y = (num && den) ? ex[lg[num] + nn - lg[den]] : 0u;
         }

@@ -302,6 +302,12 @@ __device__ __forceinline__ void interp_one(uint32_t (&acc)[8][8], const uint4 *_
   const uint4 a = ev[static_cast<unsigned long long>(J) * 128], b = ev[static_cast<unsigned long long>(J) * 128 + 1];
   const uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   interp_column<K, I0, J>(acc, e, std::make_integer_sequence<int, 8>());
+  if (J % 4 == 3) {  // cut the XOR expressions here: reassociation across all K evaluations would keep every one of them live
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[i][b]));
+  }
 }
 template <int K, int I0, int... J>
 __device__ __forceinline__ void interp_all(uint32_t (&acc)[8][8], const uint4 *__restrict__ ev, std::integer_sequence<int, J...>) {
