@@ -126,43 +126,81 @@ awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, in
   }
 }
 
-// one wave per frame: compares the decoder output with the transmitted word
+// Compares the decoder output with the transmitted word (nullptr: the all-zero word), 16 lanes per frame with one
+// 16-byte load per lane and buffer (the last lane of a frame takes the 16 bytes that END at n and masks the overlap, so
+// nothing is read past a frame), mismatching symbols counted on packed bytes, the sums of a frame combined by a DPP
+// row reduction.  The group leaders keep their counters in registers; LDS / global atomics once per wavefront.
+__device__ __forceinline__ unsigned nonzero_bytes(uint32_t x) {
+  return static_cast<unsigned>(__builtin_popcount((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u));
+}
+template <int CTRL> __device__ __forceinline__ unsigned dpp_add(unsigned v) {
+  return v + static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
 __global__ void __launch_bounds__(256)
-count_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ sent, const float *__restrict__ llr,
-             const uint16_t *__restrict__ iters, const int32_t *__restrict__ status, int n, unsigned iterations,
-             unsigned long long frames, unsigned long long *__restrict__ counters) {
+count_kernel(const uint8_t *__restrict__ hard, const uint8_t *__restrict__ sent, const uint16_t *__restrict__ iters,
+             const int32_t *__restrict__ status, int n, unsigned iterations, unsigned long long frames,
+             unsigned long long *__restrict__ counters) {
   __shared__ unsigned int acc[CC_MC_NCOUNTERS];
   if (threadIdx.x < CC_MC_NCOUNTERS) acc[threadIdx.x] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
-  for (unsigned long long f = wave; f < frames; f += nwaves) {
-    unsigned biterr = 0, cherr = 0;
-    for (int j = lane; j < n; j += 64) {
-      const unsigned s = sent ? sent[f * n + j] : 0u;
-      biterr += (hard[f * n + j] != s);
-      if (llr) cherr += ((llr[f * n + j] < 0.0f ? 1u : 0u) != s);  // (null: counted by the channel kernel)
+  const int lane = threadIdx.x & 63, sl = lane & 15;
+  const unsigned long long group = (static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 16;
+  unsigned c_frames = 0, c_bit = 0, c_word = 0, c_fail = 0, c_und = 0, c_iter = 0;  // of the frames this group saw
+  const unsigned long long trips = (frames + ngroups - 1) / ngroups;  // same trip count in every lane (DPP below)
+  for (unsigned long long tr = 0; tr < trips; ++tr) {
+    const unsigned long long f = group + tr * ngroups;
+    const bool live = f < frames;
+    unsigned cnt = 0;
+    if (live) {
+      const uint8_t *h = hard + f * n, *s = sent ? sent + f * n : nullptr;
+      if (n >= 16) {
+        for (int o = 16 * sl; o < n; o += 256) {
+          const int o2 = o + 16 > n ? n - 16 : o, skip = o - o2;  // bytes [o2, o) belong to the neighbour
+          uint32_t x[4];
+          __builtin_memcpy(x, h + o2, 16);
+          if (s) {
+            uint32_t y[4];
+            __builtin_memcpy(y, s + o2, 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] ^= y[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int sk = skip - 4 * j;
+            const uint32_t m = sk >= 4 ? 0u : sk <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * sk);
+            cnt += nonzero_bytes(x[j] & m);
+          }
+        }
+      } else if (sl < n) {
+        cnt = h[sl] != (s ? s[sl] : 0);
+      }
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-      biterr += __shfl_xor(biterr, m, 64);
-      cherr += __shfl_xor(cherr, m, 64);
-    }
-    if (lane == 0) {
+    cnt = dpp_add<0xB1>(cnt);   // quad_perm [1,0,3,2]
+    cnt = dpp_add<0x4E>(cnt);   // quad_perm [2,3,0,1]
+    cnt = dpp_add<0x141>(cnt);  // row_half_mirror
+    cnt = dpp_add<0x140>(cnt);  // row_mirror: every lane of the row holds the frame's sum
+    if (live && sl == 0) {
       const bool failed = status[f] != CC_FRAME_OK;
-      atomicAdd(&acc[CC_MC_FRAMES], 1u);
-      atomicAdd(&acc[CC_MC_BIT_ERRORS], biterr);
-      atomicAdd(&acc[CC_MC_CHANNEL_BIT_ERRORS], cherr);
-      if (failed || biterr) atomicAdd(&acc[CC_MC_WORD_ERRORS], 1u);  // simulation.c++:128-135
-      if (failed) atomicAdd(&acc[CC_MC_FAILURES], 1u);
-      if (!failed && biterr) atomicAdd(&acc[CC_MC_UNDETECTED], 1u);
+      c_frames += 1;
+      c_bit += cnt;
+      c_word += (failed || cnt) ? 1u : 0u;  // simulation.c++:128-135
+      c_fail += failed ? 1u : 0u;
+      c_und += (!failed && cnt) ? 1u : 0u;
       if (iters) {
         const unsigned it = iters[f];
-        const unsigned run = failed ? iterations : it + 1;  // iterations executed
-        atomicAdd(&acc[CC_MC_ITER_SUM], run);
+        c_iter += failed ? iterations : it + 1;  // iterations executed
         if (!failed && it <= 55) atomicAdd(&acc[CC_MC_ITER_HIST + it], 1u);
       }
     }
+  }
+  if (sl == 0 && c_frames) {
+    atomicAdd(&acc[CC_MC_FRAMES], c_frames);
+    if (c_bit) atomicAdd(&acc[CC_MC_BIT_ERRORS], c_bit);
+    if (c_word) atomicAdd(&acc[CC_MC_WORD_ERRORS], c_word);
+    if (c_fail) atomicAdd(&acc[CC_MC_FAILURES], c_fail);
+    if (c_und) atomicAdd(&acc[CC_MC_UNDETECTED], c_und);
+    if (c_iter) atomicAdd(&acc[CC_MC_ITER_SUM], c_iter);
   }
   __syncthreads();
   if (threadIdx.x < CC_MC_NCOUNTERS && acc[threadIdx.x])
@@ -291,10 +329,10 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
     else
       rc = launch_algebraic(code, true, w.llr, nullptr, nullptr, w.hard, w.nerr, w.status, m, stream);
     if (rc != CC_OK) return rc;
-    const unsigned long long blocks = (m + 3) / 4;
+    const unsigned long long blocks = (m + 15) / 16;
     const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
     hipLaunchKernelGGL(count_kernel, dim3(static_cast<int>(blocks < max_grid ? blocks : max_grid)), dim3(256), 0, stream,
-                       w.hard, sent, nullptr, code->soft ? w.iters : nullptr, w.status, n, code->desc.iterations,
+                       w.hard, sent, code->soft ? w.iters : nullptr, w.status, n, code->desc.iterations,
                        static_cast<unsigned long long>(m), reinterpret_cast<unsigned long long *>(d_counters));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "count kernel launch");
