@@ -16,10 +16,12 @@
 // bit (tests/test_gpu_algebraic.py runs both through CC_AMD_NO_CHUNK=1).
 #include <cstdlib>
 
+#include "bitplane.hpp"
 #include "cc_internal.hpp"
 #include "wave_ops.hpp"
 
 namespace ccamd {
+int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream);  // bitslice.hip
 namespace {
 
 constexpr uint32_t kLogZero = 512;  // log of 0: ex[kLogZero + anything < 512] = 0
@@ -434,6 +436,7 @@ __host__ __device__ inline BmLayout bm_layout(int t2) {
 __global__ void __launch_bounds__(256, 2)
 chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
                 uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
+                uint4 *__restrict__ lamp,
                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t *ex = smem;                                         // [1024]
@@ -553,6 +556,23 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       if (deg == 0 && LV[m * FPW + f] != 0) deg = m;
     if (f < frames) meta[first + f] = static_cast<uint16_t>(deg | (l << 8));
     for (int m = 0; m < nc; ++m) llg[(chunk * nc + m) * FPW + f] = LL[m * FPW + f];
+    // lambda_0 .. lambda_16 as planes for the Chien kernel ([block of 64 groups][m][group][8]): lane (m, half) takes the
+    // 32 bytes of coefficient m of one group as eight dwords (word j = frames 4j .. 4j+3) through the butterfly, so bit
+    // 8 (f & 3) + (f >> 2) of a plane belongs to frame f of the group
+    if (lane < 2 * 17) {
+      const int m = lane >> 1, half = lane & 1;
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < nc) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(LV + m * FPW + 32 * half);
+        const uint4 a = row[0], b = row[1];
+        w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+        bitplane::butterfly(w);
+      }
+      const unsigned long long g = 2 * chunk + half;
+      uint4 *dst = lamp + (((g >> 6) * 17 + m) * 64 + (g & 63)) * 2;
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
   }
 }
 
@@ -563,8 +583,9 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
 __global__ void __launch_bounds__(256)
 chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
-                 const unsigned long long *__restrict__ mask, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
-                 int32_t *__restrict__ status_out, unsigned long long B) {
+                 const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
+                 uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
+                 unsigned long long B) {
   // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
   // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
   constexpr uint32_t kLongZero = 8448, kLongSize = 16640;
@@ -607,6 +628,13 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
   for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
     const unsigned long long first = chunk * 64;
     unsigned long long todo = mask[chunk];
+    if (todo == 0) continue;
+    // root masks of the chunk's two groups (bitslice_chien_kernel): word p of a group, bit 8 (f & 3) + (f >> 2) = frame f
+    uint32_t rw[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rw[h][c] = roots[(2 * chunk + h) * 256 + lane + 64 * c];
     auto pop = [](unsigned long long &m) {
       const int i = m ? __builtin_ctzll(m) : -1;
       m &= m - 1;
@@ -643,13 +671,20 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
       // root search: position p is in error iff lambda(alpha^-p) = 0  (cyclic.h:126-150)
       uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
       if (status == CC_FRAME_OK) {
-        uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
-        for (int m = 0; m <= deg; ++m) {
-          const uint32_t l0 = __builtin_amdgcn_readlane(cll, m), lm = l0 >= kLogZero ? kLongZero : l0;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        if (deg <= 16) {  // searched on planes already
+          const int fi = s & 31, bit = 8 * (fi & 3) + (fi >> 2);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            acc[c] ^= exl[lm + e[c]];
-            e[c] += xinv[c];
+          for (int c = 0; c < 4; ++c) acc[c] = (((s >> 5) ? rw[1][c] : rw[0][c]) >> bit) & 1u ? 0u : 1u;
+        } else {
+          uint32_t e[4] = {0, 0, 0, 0};
+          for (int m = 0; m <= deg; ++m) {
+            const uint32_t l0 = __builtin_amdgcn_readlane(cll, m), lm = l0 >= kLogZero ? kLongZero : l0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              acc[c] ^= exl[lm + e[c]];
+              e[c] += xinv[c];
+            }
           }
         }
         uint32_t count = 0;
@@ -752,6 +787,211 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
   }
 }
 
+
+// The same stage with FOUR dirty frames per wavefront, 16 lanes each, for locators of degree <= 16 whose roots the
+// Chien kernel has already marked: what is left per frame is fixed work (operands in, root positions out of the bit
+// masks, Forney with one lane per error, status out), and chunk_fix_kernel pays it once per wavefront per frame.
+// A frame's 255-bit root vector comes from four ballots over the mask words of its group (bit = frame); lane e of a
+// quarter takes the e-th set bit as its error position.  Frames with a longer locator (never correctable within the
+// capability) are handed to chunk_fix_kernel through `left`.
+__global__ void __launch_bounds__(256)
+chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
+                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
+                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
+                  unsigned long long *__restrict__ left, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
+                  int32_t *__restrict__ status_out, unsigned long long B) {
+  constexpr uint32_t kLongZero = 8448, kLongSize = 16640, kN = 255;
+  constexpr int kScratch = 224;  // per quarter: CSL u16[32] | CS u8[32] | CLL u16[34] | OML u16[16]
+  __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 16 * kScratch + kLongSize];
+  uint8_t *ex = smem;                                         // [1024]
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
+  uint8_t *lg = smem + 1536;                                  // [256] plain log table (log 0 = 0)
+  uint8_t *exl = smem + 1792 + 16 * kScratch;
+  for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kLongZero ? T->exp[i % 255u] : 0;
+  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, sl = lane & 15;
+  const int n = T->n, t2 = T->nroots, nc = t2 + 1;
+  const bool is_rs = T->family == CC_FAMILY_RS;
+  uint8_t *base = smem + 1792 + (wid * 4 + q) * kScratch;
+  uint16_t *CSL = reinterpret_cast<uint16_t *>(base);
+  uint8_t *CS = base + 64;
+  uint16_t *CLL = reinterpret_cast<uint16_t *>(base + 96);
+  uint16_t *OML = reinterpret_cast<uint16_t *>(base + 168);
+  const uint32_t r0 = T->roots_log[0];
+  const uint32_t step = t2 > 1 ? (T->roots_log[1] + kN - r0) % kN : 0;
+
+  const unsigned long long nchunks = (B + 63) / 64;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * 64;
+    unsigned long long todo = mask[chunk], leftover = 0;
+    if (todo == 0) {
+      if (lane == 0) left[chunk] = 0;
+      continue;
+    }
+    uint32_t rw[2][4];  // root masks of the chunk's two groups: word p of a group, bit 8 (f & 3) + (f >> 2) = frame f
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rw[h][c] = roots[(2 * chunk + h) * 256 + lane + 64 * c];
+    while (todo != 0) {
+      int fs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fs[k] = todo ? __builtin_ctzll(todo) : -1;
+        todo &= todo - 1;
+      }
+      const int fq = q == 0 ? fs[0] : q == 1 ? fs[1] : q == 2 ? fs[2] : fs[3];
+      const bool act = fq >= 0;
+      const int fc = act ? fq : fs[0];  // idle quarters shadow the first frame and store nothing
+      const unsigned long long frame = first + fc;
+      const uint32_t md = meta[frame];
+      const int deg = md & 0xFF, len = md >> 8;
+      const unsigned long long group = 2 * chunk + (fc >> 5);
+      const int fi = fc & 31;
+      const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = sl + 16 * h;
+        if (j < t2) {
+          const uint32_t v = sb[j * 2048];
+          CS[j] = static_cast<uint8_t>(v);
+          CSL[j] = lg2[v];
+        }
+      }
+      for (int m = sl; m < nc; m += 16) CLL[m] = llg[(chunk * nc + m) * 64 + fc];
+
+      // the four frames' root vectors: bit p of R = "position p is a root"
+      uint32_t R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int fk = fs[k] >= 0 ? fs[k] : fs[0], fik = fk & 31, bit = 8 * (fik & 3) + (fik >> 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t w = (fk >> 5) ? rw[1][c] : rw[0][c];
+          const unsigned long long b64 = __ballot((w >> bit) & 1u);
+          if (q == k) {
+            R[2 * c] = static_cast<uint32_t>(b64);
+            R[2 * c + 1] = static_cast<uint32_t>(b64 >> 32);
+          }
+        }
+      }
+      R[7] &= 0x7FFFFFFFu;  // there is no position 255
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cnt += __builtin_popcount(R[i]);
+
+      const bool longer = deg > 16;  // searched and corrected by chunk_fix_kernel
+      {
+        const unsigned long long lm = __ballot(act && longer && sl == 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((lm >> (16 * k)) & 1ull) leftover |= 1ull << fs[k];
+      }
+      int status = CC_FRAME_OK;
+      // the PGZ tag runs as bounded-distance decoding: locator degree within capability
+      if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+      if (deg < 1) status = CC_FRAME_LOCATOR;                          // cyclic.h:145-147
+      const int nerr = static_cast<int>(cnt);
+      if (nerr != deg) status = CC_FRAME_LOCATOR;                      // cyclic.h:134-143
+      const bool live = act && !longer;
+      bool mine = live && status == CC_FRAME_OK && sl < deg;           // this lane owns the sl-th error
+
+      // position of the sl-th root (ascending, the order of cyclic::zeroes)
+      uint32_t p = 0;
+      {
+        uint32_t rem = sl, wsel = 0, word = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t c = __builtin_popcount(R[i]);
+          if (!found && rem < c) {
+            found = true;
+            word = i;
+            wsel = R[i];
+          }
+          if (!found) rem -= c;
+        }
+        mine = mine && found;
+        if (!mine) rem = 0;
+        for (; rem != 0; --rem) wsel &= wsel - 1;
+        p = 32 * word + (wsel ? __builtin_ctz(wsel) : 0);
+      }
+      uint32_t sym = 0;
+      if (mine) sym = out[frame * n + p];  // needed after the error value
+
+      // error values: bch.h:80-83 (all ones) / Forney for rs.h:41-78
+      uint32_t y = mine ? 1u : 0u;
+      const uint32_t dmax = [&] {  // longest locator among the four (wave-uniform)
+        const uint32_t dv = (live && status == CC_FRAME_OK) ? static_cast<uint32_t>(deg) : 0u;
+        uint32_t mx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t d = __builtin_amdgcn_readlane(dv, 16 * k);
+          mx = d > mx ? d : mx;
+        }
+        return mx;
+      }();
+      if (is_rs && dmax != 0) {
+        uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j = sl < deg
+        for (uint32_t m = 0; m <= dmax; ++m) {
+          const bool in = mine && static_cast<uint32_t>(sl) >= m && m <= static_cast<uint32_t>(deg) && sl - m < static_cast<uint32_t>(t2);
+          const uint32_t lm = CLL[m <= static_cast<uint32_t>(t2) ? m : 0];
+          om ^= in ? ex[lm + CSL[in ? sl - m : 0]] : 0u;
+        }
+        OML[sl] = lg2[om];  // log 0 = 512 where this lane has no coefficient
+        const uint32_t xi = p ? kN - p : 0u;  // log X^-1
+        uint32_t x2 = 2 * xi;
+        x2 = umin32(x2, x2 - kN);
+        uint32_t num = 0, den = 0, e = 0;
+        for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1); coefficients beyond this frame's degree are zero
+          const uint32_t l0 = OML[j];
+          num ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
+          e += xi;
+        }
+        e = 0;
+        for (uint32_t m = 1; m <= dmax; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+          const uint32_t l0 = CLL[m];
+          den ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
+          e += x2;
+        }
+        y = (mine && num && den) ? ex[lg[num] + kN - lg[den]] : 0u;
+      }
+      // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip), evaluated otherwise
+      if (__ballot(live && status == CC_FRAME_OK && len != deg) != 0) {
+        const uint32_t ly = lg[y];
+        uint32_t ev = (r0 * p) % kN;
+        const uint32_t dp = (step * p) % kN;
+        uint32_t mismatch = 0;
+        for (int j = 0; j < t2; ++j) {
+          uint32_t term = (mine && y) ? ex[ly + ev] : 0u;
+          ev += dp;
+          ev = ev >= kN ? ev - kN : ev;
+          term = dpp_xor<0xB1, 0xF>(term);
+          term = dpp_xor<0x4E, 0xF>(term);
+          term = dpp_xor<0x141, 0xF>(term);
+          term = dpp_xor<0x140, 0xF>(term);  // the sum over the 16 lanes of the quarter, in every lane
+          mismatch |= term ^ CS[j];
+        }
+        if (status == CC_FRAME_OK && len != deg && mismatch != 0) status = CC_FRAME_RECHECK;
+      }
+      const bool ok = status == CC_FRAME_OK;
+      if (mine && ok && y) out[frame * n + p] = static_cast<uint8_t>(sym ^ y);
+      if (live && sl == 0) {
+        if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
+        if (status_out) status_out[frame] = status;
+      }
+      __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next four frames
+    }
+    if (lane == 0) left[chunk] = leftover;
+  }
+}
+
 }  // namespace
 
 bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
@@ -806,7 +1046,15 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
   return CC_OK;
 }
 
-// syndromes on bit planes (bitslice.hip), Berlekamp-Massey over chunks of 64 frames, then the dirty frames one by one
+static bool no_fix4() {  // experiments / cross-check: CC_AMD_NO_FIX4=1 sends every dirty frame through chunk_fix_kernel
+  static const bool v = [] {
+    const char *e = std::getenv("CC_AMD_NO_FIX4");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
+// syndromes on bit planes (bitslice.hip), Berlekamp-Massey over chunks of 64 frames, root search on planes, corrections
 static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
                                   int32_t *d_status, size_t B, hipStream_t stream) {
   const int t2 = static_cast<int>(code->tab.roots.size()), nc = t2 + 1;
@@ -816,12 +1064,17 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   const size_t plane_bytes = G64 * code->tab.n * 32, synd_bytes = G64 * t2 * 32;
   const size_t llg_bytes = up(static_cast<size_t>(chunks) * nc * 64 * 2), meta_bytes = up(static_cast<size_t>(chunks) * 64 * 2);
   const size_t mask_bytes = up(static_cast<size_t>(chunks) * 8);
+  const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes, stream));
+  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws),
+                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + roots_bytes + left_bytes, stream));
   uint8_t *d_synd = ws + plane_bytes;
   uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);
   uint16_t *d_meta = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_llg) + llg_bytes);
   unsigned long long *d_mask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(d_meta) + meta_bytes);
+  uint8_t *d_lamp = reinterpret_cast<uint8_t *>(d_mask) + mask_bytes;
+  uint8_t *d_roots = d_lamp + lamp_bytes;
+  unsigned long long *d_left = reinterpret_cast<unsigned long long *>(d_roots + roots_bytes);
   int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
   if (rc == CC_OK) {
     static const int dbg_stop = [] {
@@ -840,15 +1093,26 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
                               static_cast<int>(lds));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
-                         d_mask, d_nerr, d_status, Bq);
+                         d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nerr, d_status, Bq);
       e = hipGetLastError();
     }
+    if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, stream) != CC_OK) e = hipErrorLaunchFailure;
     if (e == hipSuccess) {
       max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
       grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
-      hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
-                         code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, d_mask, d_out, d_nerr, d_status, Bq);
-      e = hipGetLastError();
+      const bool four = dbg_stop == 0 && !no_fix4();
+      if (four) {  // locators of degree <= 16, four frames per wavefront; the rest goes on through d_left
+        hipLaunchKernelGGL(chunk_fix4_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
+                           d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_roots), d_left, d_out, d_nerr,
+                           d_status, Bq);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
+                           code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, four ? d_left : d_mask,
+                           reinterpret_cast<const uint32_t *>(d_roots), d_out, d_nerr, d_status, Bq);
+        e = hipGetLastError();
+      }
     }
     if (e != hipSuccess) rc = hip_fail(e, "algebraic chunk kernels launch");
   }

@@ -24,61 +24,13 @@
 #include <cstdlib>
 #include <utility>
 
+#include "bitplane.hpp"
 #include "cc_internal.hpp"
 
 namespace ccamd {
 namespace {
 
-constexpr uint32_t kPoly = 0x11d;
-constexpr uint32_t times_alpha(uint32_t v) { return ((v << 1) & 0x100u) ? ((v << 1) ^ kPoly) : (v << 1); }
-constexpr uint32_t times_alpha_pow(uint32_t v, int J) {
-  for (int i = 0; i < J; ++i) v = times_alpha(v);
-  return v;
-}
-// does plane C of the operand enter plane B of alpha^J * operand?
-template <int J, int B, int C> struct Tap {
-  static constexpr bool value = (times_alpha_pow(1u << C, J) >> B) & 1u;
-};
-
-template <int J, int B, int... C>
-__device__ __forceinline__ uint32_t horner_plane(const uint32_t (&s)[8], uint32_t r, std::integer_sequence<int, C...>) {
-  uint32_t acc = r;
-  ((Tap<J, B, C>::value ? (void)(acc ^= s[C]) : (void)0), ...);
-  return acc;
-}
-template <int J, int... B>
-__device__ __forceinline__ void horner_planes(uint32_t (&s)[8], const uint32_t (&r)[8], std::integer_sequence<int, B...>) {
-  const uint32_t o[8] = {horner_plane<J, B>(s, r[B], std::make_integer_sequence<int, 8>())...};
-#pragma unroll
-  for (int b = 0; b < 8; ++b) s[b] = o[b];
-}
-// s <- s * alpha^J + r on 32 frames at once
-template <int J> __device__ __forceinline__ void horner(uint32_t (&s)[8], const uint32_t (&r)[8]) {
-  horner_planes<J>(s, r, std::make_integer_sequence<int, 8>());
-}
-
-// 8 words x 32 bits: exchange bit s of the word index with bit s of the bit position, s = 0, 1, 2 (an involution)
-__device__ __forceinline__ void butterfly(uint32_t (&w)[8]) {
-#pragma unroll
-  for (int k = 0; k < 8; k += 2) {
-    const uint32_t t = ((w[k] >> 1) ^ w[k + 1]) & 0x55555555u;
-    w[k + 1] ^= t;
-    w[k] ^= t << 1;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (k & 2) continue;
-    const uint32_t t = ((w[k] >> 2) ^ w[k + 2]) & 0x33333333u;
-    w[k + 2] ^= t;
-    w[k] ^= t << 2;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t t = ((w[k] >> 4) ^ w[k + 4]) & 0x0F0F0F0Fu;
-    w[k + 4] ^= t;
-    w[k] ^= t << 4;
-  }
-}
+using namespace bitplane;
 
 // One wavefront per group of 32 frames.  Lane l owns the four positions q .. q+3, q = min(4 l, n - 4): one (unaligned)
 // dword per frame and lane instead of four byte loads -- the byte form was bound by the rate of the memory
@@ -362,6 +314,95 @@ bitslice_parity_kernel(const uint4 *__restrict__ evals, uint8_t *__restrict__ cw
   }
 }
 
+// ---------------- root search on planes ----------------
+// lambda(alpha^-p) for p = 0 .. 254 as a Chien search: the terms T_m = lambda_m alpha^(-m p) advance by the constant
+// alpha^(-m) = alpha^(255 - m) per position -- sixteen fixed XOR networks -- and their sum is tested for zero on all 32
+// frames of a group at once: bit i of the mask word of (group, p) says "p is a root" for the frame with
+// i = 8 (f & 3) + (f >> 2) (the order chunk_bm_kernel transposes in).  Coefficients 0 .. 16; frames whose locator is
+// longer are searched by chunk_fix_kernel itself.  Wavefront = 64 groups x 32 positions (segment SEG starts at
+// p = 32 SEG with T_m advanced by alpha^(-32 m SEG)), so a lane writes one 128-byte line of masks[group][256].
+constexpr int kChienCoef = 17;
+// rows of the 8 x 8 binary matrices of "times alpha^(-32 m seg)", m = 1 .. 16, seg = 0 .. 7: the advance of T_m to the
+// first position of a segment is the one multiplication whose constant differs from wavefront to wavefront, so it
+// runs as a masked sum (plane c enters plane b under a wave-uniform mask) instead of a hard-wired network
+struct ChienAdvance {
+  uint8_t row[8][kChienCoef - 1][8];
+  constexpr ChienAdvance() : row{} {
+    Gf256 f;
+    for (int seg = 0; seg < 8; ++seg)
+      for (int m = 1; m < kChienCoef; ++m) {
+        const int e = ((255 - m) * 32 * seg) % 255;
+        for (int b = 0; b < 8; ++b) {
+          uint32_t r = 0;
+          for (int c = 0; c < 8; ++c) r |= ((static_cast<uint32_t>(f.exp[(e + c) % 255]) >> b) & 1u) << c;  // alpha^e x^c
+          row[seg][m - 1][b] = static_cast<uint8_t>(r);
+        }
+      }
+  }
+};
+__constant__ constexpr ChienAdvance kChienAdvance{};
+
+template <int... M>
+__device__ __forceinline__ void chien_step(uint32_t (&T)[kChienCoef][8], std::integer_sequence<int, M...>) {
+  const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (horner<255 - (M + 1)>(T[M + 1], zero), ...);
+}
+__global__ void __launch_bounds__(256)
+bitslice_chien_kernel(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, unsigned long long G) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long blk = blockIdx.x >> 1;
+  const int seg = static_cast<int>(blockIdx.x & 1) * 4 + wid;
+  const unsigned long long g = blk * 64 + lane;
+  if (g >= G) return;
+  uint32_t T[kChienCoef][8];
+#pragma unroll
+  for (int m = 0; m < kChienCoef; ++m) {
+    const uint4 *src = lamp + ((blk * kChienCoef + m) * 64 + lane) * 2;
+    const uint4 a = src[0], b = src[1];
+    T[m][0] = a.x, T[m][1] = a.y, T[m][2] = a.z, T[m][3] = a.w;
+    T[m][4] = b.x, T[m][5] = b.y, T[m][6] = b.z, T[m][7] = b.w;
+  }
+  if (seg != 0) {
+#pragma unroll
+    for (int m = 1; m < kChienCoef; ++m) {
+      uint32_t o[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t row = kChienAdvance.row[seg][m - 1][b];  // wave-uniform
+        uint32_t acc = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc ^= T[m][c] & (0u - ((row >> c) & 1u));
+        o[b] = acc;
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) T[m][b] = o[b];
+    }
+  }
+  using Sixteen = std::make_integer_sequence<int, kChienCoef - 1>;
+  for (int pp = 0; pp < 32; pp += 2) {  // two positions per trip: the in-place update needs no register copies
+    uint32_t out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint32_t nz = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        uint32_t sum = T[0][b];
+#pragma unroll
+        for (int m = 1; m < kChienCoef; ++m) sum ^= T[m][b];
+        nz |= sum;
+      }
+      out[u] = ~nz;
+      chien_step(T, Sixteen());
+      // keep the steps apart: flattened over several steps the XOR networks grow into sums over every earlier plane
+#pragma unroll
+      for (int m = 1; m < kChienCoef; ++m)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(T[m][b]));
+    }
+    masks[g * 128 + 16 * seg + (pp >> 1)] = make_uint2(out[0], out[1]);
+  }
+}
+
 }  // namespace
 
 bool bitslice_supported(const cc_code *code) {
@@ -399,6 +440,16 @@ int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_
                      stream, static_cast<const uint4 *>(d_planes), d_synd, G, n, t2, 0);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice syndrome kernel launch");
+  return CC_OK;
+}
+
+// lamp: G64 * 17 * 32 bytes (chunk_bm_kernel), masks: G64 * 256 words
+int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream) {
+  const unsigned long long G = (B + 31) / 32;
+  hipLaunchKernelGGL(bitslice_chien_kernel, dim3(static_cast<unsigned>(2 * ((G + 63) / 64))), dim3(256), 0, stream,
+                     static_cast<const uint4 *>(d_lamp), static_cast<uint2 *>(d_masks), G);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "bitslice chien kernel launch");
   return CC_OK;
 }
 
