@@ -419,21 +419,22 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
 // a time through chains of dependent table look-ups and wants many wavefronts: its own kernel with 0.3 KB of LDS
 // per wavefront.  lambda (logs), deg / L and the dirty masks travel through HBM (70 B per frame).
 struct BmLayout {
-  int SL, LL, BL, SV, LV, bytes;
+  int SL, LL, BL, bytes;
 };
 __host__ __device__ inline BmLayout bm_layout(int t2) {
   BmLayout c;
   const int nc = t2 + 1;
   c.SL = 0;                     // u16 [t2][64]  log S_j
   c.LL = c.SL + 2 * t2 * 64;    // u16 [nc][64]  log lambda_m
-  c.BL = c.LL + 2 * nc * 64;    // u16 [nc][64]  log b_m
-  c.SV = c.BL + 2 * nc * 64;    // u8  [t2][64]  S_j
-  c.LV = c.SV + t2 * 64;        // u8  [nc][64]  lambda_m
-  c.bytes = (c.LV + nc * 64 + 15) & ~15;
+  c.BL = c.LL + 2 * nc * 64;    // u16 [nc][64]  log b_m (after the recurrence: lambda_0 .. lambda_16 as bytes)
+  c.bytes = (c.BL + 2 * nc * 64 + 15) & ~15;
   return c;
 }
 
-__global__ void __launch_bounds__(256, 2)
+// Everything in the log domain (log 0 = 512, antilog table zero above 510): 12.3 KB of LDS per wavefront for 2t = 32,
+// three wavefronts per SIMD -- the stage is bound by the latency of its dependent LDS operations, so occupancy is
+// what it is sized for.
+__global__ void __launch_bounds__(256, 3)
 chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
                 uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
                 uint4 *__restrict__ lamp,
@@ -452,7 +453,6 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
   uint16_t *SL = reinterpret_cast<uint16_t *>(base + lay.SL);
   uint16_t *LL = reinterpret_cast<uint16_t *>(base + lay.LL);
   uint16_t *BL = reinterpret_cast<uint16_t *>(base + lay.BL);
-  uint8_t *SV = base + lay.SV, *LV = base + lay.LV;
 
   const unsigned long long nchunks = (B + FPW - 1) / FPW;
   const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
@@ -468,7 +468,6 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
 #pragma unroll 8
     for (int j = 0; j < t2; ++j) {
       const uint32_t v = src[j * 2048];
-      SV[j * FPW + f] = static_cast<uint8_t>(v);
       SL[j * FPW + f] = lg2[v];
       any |= v;
     }
@@ -483,7 +482,6 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
 
     // Berlekamp-Massey, one lane per frame (hard_decision.h:116-155)
     for (int m = 0; m < nc; ++m) {  // lambda = b = 1
-      LV[m * FPW + f] = m == 0;
       LL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
       BL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
     }
@@ -491,7 +489,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
     for (int i = 0; i < t2; ++i) {
       shift += 1;  // b = b * x, :134
       const int lw = static_cast<int>(wave_umax(mine ? static_cast<uint32_t>(l) : 0u));
-      uint32_t d = SV[i * FPW + f];
+      uint32_t d = ex[SL[i * FPW + f]];
       const int mm = i < lw ? i : lw;
       // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of four adds zeros
       for (int m0 = 1; m0 <= mm; m0 += 4) {
@@ -513,31 +511,26 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       const int cap = static_cast<int>(wave_umax(upd ? static_cast<uint32_t>(lnew) : 0u));
       if (__any(upd)) {
         // lambda += d * b * x^shift, and where the register grows b := lambda_old / d; descending m so that the
-        // shifted reads of the old b (index m - shift < m) happen before that index is overwritten
-        // four coefficients per trip, all reads before the look-ups before the writes: the stage is bound by the
-        // latency of its dependent LDS operations, and a read of b at m - shift always precedes the write of that
-        // index in the sequential order too
+        // shifted reads of the old b (index m - shift < m) happen before that index is overwritten.
+        // Four coefficients per trip, all reads before the look-ups before the writes: a read of b at m - shift
+        // always precedes the write of that index in the sequential order too.
         for (int m1 = cap; m1 >= 0; m1 -= 4) {
-          uint32_t lold[4], lv[4], bt[4], nv[4], ln[4];
+          uint32_t lold[4], bt[4], nv[4], ln[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int m = m1 - u > 0 ? m1 - u : 0, bi = m1 - u - shift;
             lold[u] = LL[m * FPW + f];
-            lv[u] = LV[m * FPW + f];
             bt[u] = bi >= 0 ? BL[(bi >= 0 ? bi : 0) * FPW + f] : kLogZero;
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) nv[u] = lv[u] ^ ex[ld + bt[u]];
+          for (int u = 0; u < 4; ++u) nv[u] = ex[lold[u]] ^ ex[ld + bt[u]];
 #pragma unroll
           for (int u = 0; u < 4; ++u) ln[u] = lg2[nv[u]];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int m = m1 - u;
             if (m < 0) break;  // wave-uniform
-            if (upd) {
-              LV[m * FPW + f] = static_cast<uint8_t>(nv[u]);
-              LL[m * FPW + f] = static_cast<uint16_t>(ln[u]);
-            }
+            if (upd) LL[m * FPW + f] = static_cast<uint16_t>(ln[u]);
             if (grow) {
               uint32_t q = lold[u] + linv;
               q = q >= static_cast<uint32_t>(nn) ? q - nn : q;
@@ -553,12 +546,15 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
     }
     int deg = 0;
     for (int m = t2; m >= 1; --m)
-      if (deg == 0 && LV[m * FPW + f] != 0) deg = m;
+      if (deg == 0 && LL[m * FPW + f] != kLogZero) deg = m;
     if (f < frames) meta[first + f] = static_cast<uint16_t>(deg | (l << 8));
     for (int m = 0; m < nc; ++m) llg[(chunk * nc + m) * FPW + f] = LL[m * FPW + f];
-    // lambda_0 .. lambda_16 as planes for the Chien kernel ([block of 64 groups][m][group][8]): lane (m, half) takes the
-    // 32 bytes of coefficient m of one group as eight dwords (word j = frames 4j .. 4j+3) through the butterfly, so bit
-    // 8 (f & 3) + (f >> 2) of a plane belongs to frame f of the group
+    // lambda_0 .. lambda_16 as planes for the Chien kernel ([block of 64 groups][m][group][8]): the values go to the
+    // (now free) b area as bytes [m][64]; lane (m, half) takes the 32 bytes of coefficient m of one group as eight
+    // dwords (word j = frames 4j .. 4j+3) through the butterfly, so bit 8 (f & 3) + (f >> 2) of a plane belongs to
+    // frame f of the group
+    uint8_t *LV = reinterpret_cast<uint8_t *>(BL);
+    for (int m = 0; m < 17 && m < nc; ++m) LV[m * FPW + f] = ex[LL[m * FPW + f]];
     if (lane < 2 * 17) {
       const int m = lane >> 1, half = lane & 1;
       uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
