@@ -303,7 +303,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
         uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
         if (status == CC_FRAME_OK) {
           uint32_t acc[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
-#pragma unroll 2
           for (int m = 0; m <= deg; ++m) {
             const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
 #pragma unroll
@@ -333,7 +332,6 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
           for (int c = 0; c < 4; ++c)
             if (isroot[c]) RP[rank[c]] = static_cast<uint8_t>(lane + 64 * c);
           uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j < deg
-#pragma unroll 2
           for (int m = 0; m <= deg; ++m) {
             const uint32_t lm = __builtin_amdgcn_readlane(cll, m);
             const bool in = lane >= m && lane < deg && lane - m < t2;
@@ -347,14 +345,12 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
             uint32_t x2 = 2 * xi;
             x2 = umin32(x2, x2 - static_cast<uint32_t>(nn));
             uint32_t num = 0, den = 0, e = 0;
-#pragma unroll 2
             for (int j = 0; j < deg; ++j) {  // omega(X^-1)
               num ^= ex[__builtin_amdgcn_readlane(oml, j) + e];
               e += xi;
               e = umin32(e, e - static_cast<uint32_t>(nn));
             }
             e = 0;
-#pragma unroll 2
             for (int m = 1; m <= deg; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
               den ^= ex[__builtin_amdgcn_readlane(cll, m) + e];
               e += x2;
@@ -445,7 +441,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
   for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
   lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
   __syncthreads();
-  constexpr int FPW = 64;
+  constexpr int FPW = 64, U = 4;  // U coefficients per trip of the two inner loops (8: measured slower)
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = lane;
   const int nn = T->n, t2 = T->nroots, nc = t2 + 1;
   const BmLayout lay = bm_layout(t2);
@@ -491,17 +487,17 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       const int lw = static_cast<int>(wave_umax(mine ? static_cast<uint32_t>(l) : 0u));
       uint32_t d = ex[SL[i * FPW + f]];
       const int mm = i < lw ? i : lw;
-      // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of four adds zeros
-      for (int m0 = 1; m0 <= mm; m0 += 4) {
-        uint32_t la[4], sa[4];
+      // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of U adds zeros
+      for (int m0 = 1; m0 <= mm; m0 += U) {
+        uint32_t la[U], sa[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int m = m0 + u < nc ? m0 + u : nc - 1;
           la[u] = LL[m * FPW + f];
           sa[u] = SL[(i - m > 0 ? i - m : 0) * FPW + f];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d ^= ex[la[u] + sa[u]];
+        for (int u = 0; u < U; ++u) d ^= ex[la[u] + sa[u]];
       }
       const bool upd = mine && d != 0;
       const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
@@ -512,22 +508,22 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       if (__any(upd)) {
         // lambda += d * b * x^shift, and where the register grows b := lambda_old / d; descending m so that the
         // shifted reads of the old b (index m - shift < m) happen before that index is overwritten.
-        // Four coefficients per trip, all reads before the look-ups before the writes: a read of b at m - shift
+        // U coefficients per trip, all reads before the look-ups before the writes: a read of b at m - shift
         // always precedes the write of that index in the sequential order too.
-        for (int m1 = cap; m1 >= 0; m1 -= 4) {
-          uint32_t lold[4], bt[4], nv[4], ln[4];
+        for (int m1 = cap; m1 >= 0; m1 -= U) {
+          uint32_t lold[U], bt[U], nv[U], ln[U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int m = m1 - u > 0 ? m1 - u : 0, bi = m1 - u - shift;
             lold[u] = LL[m * FPW + f];
             bt[u] = bi >= 0 ? BL[(bi >= 0 ? bi : 0) * FPW + f] : kLogZero;
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) nv[u] = ex[lold[u]] ^ ex[ld + bt[u]];
+          for (int u = 0; u < U; ++u) nv[u] = ex[lold[u]] ^ ex[ld + bt[u]];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) ln[u] = lg2[nv[u]];
+          for (int u = 0; u < U; ++u) ln[u] = lg2[nv[u]];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int m = m1 - u;
             if (m < 0) break;  // wave-uniform
             if (upd) LL[m * FPW + f] = static_cast<uint16_t>(ln[u]);
@@ -935,6 +931,7 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
       }();
       if (is_rs && dmax != 0) {
         uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j = sl < deg
+#pragma unroll 4
         for (uint32_t m = 0; m <= dmax; ++m) {
           const bool in = mine && static_cast<uint32_t>(sl) >= m && m <= static_cast<uint32_t>(deg) && sl - m < static_cast<uint32_t>(t2);
           const uint32_t lm = CLL[m <= static_cast<uint32_t>(t2) ? m : 0];
@@ -945,12 +942,14 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         uint32_t x2 = 2 * xi;
         x2 = umin32(x2, x2 - kN);
         uint32_t num = 0, den = 0, e = 0;
+#pragma unroll 4
         for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1); coefficients beyond this frame's degree are zero
           const uint32_t l0 = OML[j];
           num ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
           e += xi;
         }
         e = 0;
+#pragma unroll 4
         for (uint32_t m = 1; m <= dmax; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
           const uint32_t l0 = CLL[m];
           den ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
