@@ -433,9 +433,10 @@ __host__ __device__ inline BmLayout bm_layout(int t2) {
 __global__ void __launch_bounds__(256, 3)
 chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
                 uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
-                uint4 *__restrict__ lamp,
+                uint4 *__restrict__ lamp, uint32_t *__restrict__ nleft,
                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;  // chunks chunk_fix4_kernel will hand on (it runs after this kernel)
   uint8_t *ex = smem;                                         // [1024]
   uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
   for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
@@ -576,8 +577,9 @@ __global__ void __launch_bounds__(256)
 chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
-                 uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
-                 unsigned long long B) {
+                 const uint32_t *__restrict__ nleft, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
+                 int32_t *__restrict__ status_out, unsigned long long B) {
+  if (nleft && *nleft == 0) return;  // nothing was handed on by chunk_fix4_kernel (the usual case)
   // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
   // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
   constexpr uint32_t kLongZero = 8448, kLongSize = 16640;
@@ -790,8 +792,8 @@ __global__ void __launch_bounds__(256)
 chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                   const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                   const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
-                  unsigned long long *__restrict__ left, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
-                  int32_t *__restrict__ status_out, unsigned long long B) {
+                  unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, uint8_t *__restrict__ out,
+                  int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   constexpr uint32_t kLongZero = 8448, kLongSize = 16640, kN = 255;
   constexpr int kScratch = 224;  // per quarter: CSL u16[32] | CS u8[32] | CLL u16[34] | OML u16[16]
   __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 16 * kScratch + kLongSize];
@@ -983,7 +985,10 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
       }
       __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next four frames
     }
-    if (lane == 0) left[chunk] = leftover;
+    if (lane == 0) {
+      left[chunk] = leftover;
+      if (leftover) atomicAdd(nleft, 1u);
+    }
   }
 }
 
@@ -1062,7 +1067,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
   CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws),
-                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + roots_bytes + left_bytes, stream));
+                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + roots_bytes + left_bytes + 256, stream));
   uint8_t *d_synd = ws + plane_bytes;
   uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);
   uint16_t *d_meta = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_llg) + llg_bytes);
@@ -1070,6 +1075,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   uint8_t *d_lamp = reinterpret_cast<uint8_t *>(d_mask) + mask_bytes;
   uint8_t *d_roots = d_lamp + lamp_bytes;
   unsigned long long *d_left = reinterpret_cast<unsigned long long *>(d_roots + roots_bytes);
+  uint32_t *d_nleft = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_left) + left_bytes);
   int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
   if (rc == CC_OK) {
     static const int dbg_stop = [] {
@@ -1088,7 +1094,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
                               static_cast<int>(lds));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
-                         d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nerr, d_status, Bq);
+                         d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       e = hipGetLastError();
     }
     if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, stream) != CC_OK) e = hipErrorLaunchFailure;
@@ -1098,14 +1104,15 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
       const bool four = dbg_stop == 0 && !no_fix4();
       if (four) {  // locators of degree <= 16, four frames per wavefront; the rest goes on through d_left
         hipLaunchKernelGGL(chunk_fix4_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
-                           d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_roots), d_left, d_out, d_nerr,
-                           d_status, Bq);
+                           d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_roots), d_left, d_nleft, d_out,
+                           d_nerr, d_status, Bq);
         e = hipGetLastError();
       }
       if (e == hipSuccess) {
         hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
                            code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, four ? d_left : d_mask,
-                           reinterpret_cast<const uint32_t *>(d_roots), d_out, d_nerr, d_status, Bq);
+                           reinterpret_cast<const uint32_t *>(d_roots), four ? d_nleft : nullptr, d_out, d_nerr, d_status,
+                           Bq);
         e = hipGetLastError();
       }
     }
