@@ -833,32 +833,58 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int c = 0; c < 4; ++c) rw[h][c] = roots[(2 * chunk + h) * 256 + lane + 64 * c];
-    while (todo != 0) {
+    // The operands of the NEXT four frames (deg / L, two syndromes and up to three locator coefficients per lane) are
+    // requested before the current four are worked on: their HBM / L2 latency is off the dependent chain.
+    struct Four {
       int fs[4];
+    };
+    auto take4 = [&]() {
+      Four s;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        fs[k] = todo ? __builtin_ctzll(todo) : -1;
+        s.fs[k] = todo ? __builtin_ctzll(todo) : -1;
         todo &= todo - 1;
       }
-      const int fq = q == 0 ? fs[0] : q == 1 ? fs[1] : q == 2 ? fs[2] : fs[3];
-      const bool act = fq >= 0;
-      const int fc = act ? fq : fs[0];  // idle quarters shadow the first frame and store nothing
-      const unsigned long long frame = first + fc;
-      const uint32_t md = meta[frame];
-      const int deg = md & 0xFF, len = md >> 8;
+      return s;
+    };
+    auto mine_of = [&](const Four &s) {
+      const int fq = q == 0 ? s.fs[0] : q == 1 ? s.fs[1] : q == 2 ? s.fs[2] : s.fs[3];
+      return fq >= 0 ? fq : s.fs[0];  // idle quarters shadow the first frame and store nothing
+    };
+    auto request = [&](const Four &s, uint32_t &md, uint32_t (&sv)[2], uint32_t (&lv)[3]) {
+      const int fc = mine_of(s);
+      md = meta[first + fc];
       const unsigned long long group = 2 * chunk + (fc >> 5);
       const int fi = fc & 31;
       const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
 #pragma unroll
+      for (int h = 0; h < 2; ++h) sv[h] = sl + 16 * h < t2 ? sb[(sl + 16 * h) * 2048] : 0u;
+#pragma unroll
+      for (int h = 0; h < 3; ++h) lv[h] = sl + 16 * h < nc ? llg[(chunk * nc + sl + 16 * h) * 64 + fc] : 0u;
+    };
+    Four cur = take4();
+    uint32_t md = 0, sv[2] = {0, 0}, lv[3] = {0, 0, 0};
+    request(cur, md, sv, lv);
+    while (cur.fs[0] >= 0) {
+      const int(&fs)[4] = cur.fs;
+      const int fq = q == 0 ? fs[0] : q == 1 ? fs[1] : q == 2 ? fs[2] : fs[3];
+      const bool act = fq >= 0;
+      const int fc = act ? fq : fs[0];
+      const unsigned long long frame = first + fc;
+      const int deg = md & 0xFF, len = md >> 8;
+#pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = sl + 16 * h;
         if (j < t2) {
-          const uint32_t v = sb[j * 2048];
-          CS[j] = static_cast<uint8_t>(v);
-          CSL[j] = lg2[v];
+          CS[j] = static_cast<uint8_t>(sv[h]);
+          CSL[j] = lg2[sv[h]];
         }
       }
-      for (int m = sl; m < nc; m += 16) CLL[m] = llg[(chunk * nc + m) * 64 + fc];
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+        if (sl + 16 * h < nc) CLL[sl + 16 * h] = static_cast<uint16_t>(lv[h]);
+      const Four nxt = take4();
+      if (nxt.fs[0] >= 0) request(nxt, md, sv, lv);
 
       // the four frames' root vectors: bit p of R = "position p is a root"
       uint32_t R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -984,6 +1010,7 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         if (status_out) status_out[frame] = status;
       }
       __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next four frames
+      cur = nxt;
     }
     if (lane == 0) {
       left[chunk] = leftover;
