@@ -483,9 +483,9 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       BL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
     }
     int l = 0, shift = 0;  // b is stored unshifted; b(x) x^shift is the polynomial of the recurrence
+    int lw = 0;            // longest register in the wavefront: max(lw, cap) after every step (cap covers all that grew)
     for (int i = 0; i < t2; ++i) {
       shift += 1;  // b = b * x, :134
-      const int lw = static_cast<int>(wave_umax(mine ? static_cast<uint32_t>(l) : 0u));
       uint32_t d = ex[SL[i * FPW + f]];
       const int mm = i < lw ? i : lw;
       // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of U adds zeros
@@ -540,6 +540,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
         l = lnew;
         shift = 0;
       }
+      lw = cap > lw ? cap : lw;
     }
     int deg = 0;
     for (int m = t2; m >= 1; --m)
