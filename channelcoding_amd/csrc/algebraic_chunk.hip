@@ -1031,7 +1031,7 @@ bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
   // measured (profiles/tools/rs_bench.py): with few syndromes the per-frame work is dominated by the frame's
   // load/store latency and the one-wavefront-per-frame kernel with its higher occupancy wins
   // (BCH(255,231), 6 syndromes: 1128 vs 899 M frames/s); with 32 syndromes this kernel wins (309 vs 220)
-  if (code->tab.roots.size() < 8) return false;
+  if (code->tab.roots.size() < 8 && !bitslice_supported(code)) return false;
   return code->desc.algorithm == CC_ALG_BM || code->desc.algorithm == CC_ALG_PGZ;
 }
 
