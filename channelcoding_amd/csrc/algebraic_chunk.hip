@@ -15,6 +15,8 @@
 // Erasures and the Euklid tag stay on algebraic_kernel (algebraic.hip).  Same results as that kernel bit for
 // bit (tests/test_gpu_algebraic.py runs both through CC_AMD_NO_CHUNK=1).
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "bitplane.hpp"
 #include "cc_internal.hpp"
@@ -570,6 +572,150 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
   }
 }
 
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant
+// expression in the body (register arrays need that)
+template <class F, int... I> __device__ __forceinline__ void for_each_index_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void for_each_index(F &&f) {
+  for_each_index_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>());
+}
+
+// The same recurrence with lambda, b and the syndromes in REGISTERS (logs), for 2t = T2 known at compile time: the 2t
+// steps and both inner loops are unrolled, so every coefficient has a fixed register and the only LDS traffic left
+// is the table look-ups -- four dependent LDS latencies per step instead of one per coefficient group.  b is kept as
+// B = b x^shift: the multiplication by x that every frame performs at every step is a renaming of registers
+// (coefficient k of B lives in P[(k - i) mod (T2 + 1)] at step i), a frame whose register grows overwrites B with
+// lambda_old / d in place.  Blocks of four coefficients are skipped under wave-uniform bounds (longest register /
+// longest update in the wavefront), as in chunk_bm_kernel.
+template <int T2>
+__global__ void __launch_bounds__(256, 3)
+chunk_bm_reg_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
+                    uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
+                    uint4 *__restrict__ lamp, uint32_t *__restrict__ nleft, int32_t *__restrict__ nerr_out,
+                    int32_t *__restrict__ status_out, unsigned long long B) {
+  constexpr int NC = T2 + 1, FPW = 64;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[1536 + 4 * 17 * 64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;
+  uint8_t *ex = smem;                                         // [1024]
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
+  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = lane;
+  const uint32_t nn = static_cast<uint32_t>(T->n);
+  uint8_t *LV = smem + 1536 + wid * (17 * 64);  // lambda_0 .. lambda_16 as bytes [m][64] for the transposition
+
+  const unsigned long long nchunks = (B + FPW - 1) / FPW;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * FPW;
+    const int frames = static_cast<int>((B - first) < static_cast<unsigned long long>(FPW) ? (B - first) : FPW);
+    const unsigned long long group = 2 * chunk + (f >> 5);
+    const int fi = f & 31;
+    const uint8_t *src = synd + ((group >> 6) * T2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+    uint32_t sl[T2];  // log S_j
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < T2; ++j) {
+      const uint32_t v = src[j * 2048];
+      any |= v;
+      sl[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < T2; ++j) sl[j] = lg2[sl[j]];
+    const unsigned long long smask = dbg_stop == 1 ? 0ull : __ballot(any != 0 && f < frames);
+    const bool mine = (smask >> lane) & 1ull;
+    if (f < frames && !mine) {  // a codeword: done (cyclic.h:225-231)
+      if (nerr_out) nerr_out[first + f] = 0;
+      if (status_out) status_out[first + f] = CC_FRAME_OK;
+    }
+    if (lane == 0) mask[chunk] = smask;
+    if (smask == 0) continue;  // wave-uniform
+
+    uint32_t ll[NC], P[NC];  // log lambda_m; log of B's coefficients, renamed every step
+#pragma unroll
+    for (int m = 0; m < NC; ++m) ll[m] = P[m] = m == 0 ? 0u : kLogZero;
+    int l = 0, lw = 0;
+    for_each_index<T2>([&](auto step) {
+      constexpr int i = decltype(step)::value;
+      // B <- B x: coefficient k of B is P[(k - (i + 1)) mod NC] from here on (k = 0 takes the slot of k = T2, zero)
+      auto Bk = [&](int k) -> uint32_t & { return P[((k - (i + 1)) % NC + NC) % NC]; };
+      uint32_t d = ex[sl[i]];
+      // discrepancy :139-141; lambda_m = 0 beyond L <= i
+#pragma unroll
+      for (int m0 = 1; m0 <= i; m0 += 4) {
+        if (m0 <= lw) {  // wave-uniform
+#pragma unroll
+          for (int m = m0; m < m0 + 4 && m <= i; ++m) d ^= ex[ll[m] + sl[i - m]];
+        }
+      }
+      const bool upd = mine && d != 0;
+      const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
+      const uint32_t ld = lg2[d];
+      const uint32_t linv = nn - ld;  // log of d^-1 (or nn for d = 1: wrapped below)
+      const int lnew = grow ? i + 1 - l : l;
+      const int cap = static_cast<int>(wave_umax(upd ? static_cast<uint32_t>(lnew) : 0u));
+      if (__any(upd)) {
+        // lambda += d B, and where the register grows B := lambda_old / d
+#pragma unroll
+        for (int m0 = 0; m0 <= i + 1 && m0 < NC; m0 += 4) {
+          if (m0 <= cap) {  // wave-uniform
+            uint32_t nv[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int m = m0 + u;
+              if (m <= i + 1 && m < NC) nv[u] = ex[ll[m]] ^ ex[ld + Bk(m)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ln[u] = lg2[nv[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // selects, not branches: upd / grow differ from lane to lane
+              const int m = m0 + u;
+              if (m <= i + 1 && m < NC) {
+                const uint32_t lold = ll[m];
+                uint32_t qv = lold + linv;
+                qv = qv >= nn ? qv - nn : qv;
+                qv = lold >= kLogZero ? kLogZero : qv;
+                Bk(m) = grow ? qv : Bk(m);
+                ll[m] = upd ? ln[u] : lold;
+              }
+            }
+          }
+        }
+      }
+      if (grow) l = lnew;
+      lw = cap > lw ? cap : lw;
+    });
+    int deg = 0;
+#pragma unroll
+    for (int m = T2; m >= 1; --m)
+      if (deg == 0 && ll[m] != kLogZero) deg = m;
+    if (f < frames) meta[first + f] = static_cast<uint16_t>(deg | (l << 8));
+#pragma unroll
+    for (int m = 0; m < NC; ++m) llg[(chunk * NC + m) * FPW + f] = static_cast<uint16_t>(ll[m]);
+    // lambda_0 .. lambda_16 as planes for the Chien kernel (see chunk_bm_kernel)
+#pragma unroll
+    for (int m = 0; m < 17 && m < NC; ++m) LV[m * FPW + f] = ex[ll[m]];
+    if (lane < 2 * 17) {
+      const int m = lane >> 1, half = lane & 1;
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < NC) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(LV + m * FPW + 32 * half);
+        const uint4 a = row[0], b = row[1];
+        w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+        bitplane::butterfly(w);
+      }
+      const unsigned long long g = 2 * chunk + half;
+      uint4 *dst = lamp + (((g >> 6) * 17 + m) * 64 + (g & 63)) * 2;
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // roots, error values, re-check and the patch of `out` (which already holds the received words), one dirty frame
 // of a 64-frame chunk at a time.  All polynomial arithmetic on logs with log 0 = 512 (no zero tests): a term
 // lambda_m X^-m is ex[log lambda_m + (m * log X^-1 mod nn)], the exponent advancing by one add + one wrap per
@@ -1120,9 +1266,22 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
     if (lds > 48 * 1024)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chunk_bm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds));
+    static const bool no_reg = [] {
+      const char *v = std::getenv("CC_AMD_NO_BM_REG");
+      return v && v[0] == '1';
+    }();
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
-                         d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
+      const unsigned long long reg_cap = static_cast<unsigned long long>(code->num_cus) * 3;
+      const int reg_grid = static_cast<int>(blocks_needed < reg_cap ? blocks_needed : reg_cap);
+      if (t2 == 32 && !no_reg)
+        hipLaunchKernelGGL((chunk_bm_reg_kernel<32>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
+                           d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
+      else if (t2 == 16 && !no_reg)
+        hipLaunchKernelGGL((chunk_bm_reg_kernel<16>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
+                           d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
+      else
+        hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
+                           d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       e = hipGetLastError();
     }
     if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, stream) != CC_OK) e = hipErrorLaunchFailure;
