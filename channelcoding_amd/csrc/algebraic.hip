@@ -393,10 +393,10 @@ int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t
   const size_t n = code->tab.n;
   uint8_t *in0 = nullptr, *in1 = nullptr, *out1 = nullptr;
   int32_t *aux = nullptr;  // nerr0, st0 (when the caller passed none), nerr1, st1
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&in0), 3 * B * n, stream));
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&in0), 3 * B * n, stream));
   in1 = in0 + B * n;
   out1 = in1 + B * n;
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&aux), 4 * B * sizeof(int32_t), stream));
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&aux), 4 * B * sizeof(int32_t), stream));
   int32_t *nerr0 = d_nerr ? d_nerr : aux, *st0 = d_status ? d_status : aux + B, *nerr1 = aux + 2 * B, *st1 = aux + 3 * B;
   const unsigned long long Bq = B;
   const int grid = code->num_cus * 8;

@@ -1105,30 +1105,29 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         return mx;
       }();
       if (is_rs && dmax != 0) {
+        const uint32_t xi = p ? kN - p : 0u;  // log X^-1
+        uint32_t x2 = 2 * xi;
+        x2 = umin32(x2, x2 - kN);
         uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j = sl < deg
+        uint32_t num = 0, den = 0, e = 0, e2 = 0;
+        // one pass over the locator: the omega coefficient of this lane, and lambda'(X^-1) = sum_{m odd} lambda_m
+        // X^-(m-1) for this lane's error (the two look-up chains overlap)
 #pragma unroll 4
         for (uint32_t m = 0; m <= dmax; ++m) {
           const bool in = mine && static_cast<uint32_t>(sl) >= m && m <= static_cast<uint32_t>(deg) && sl - m < static_cast<uint32_t>(t2);
           const uint32_t lm = CLL[m <= static_cast<uint32_t>(t2) ? m : 0];
           om ^= in ? ex[lm + CSL[in ? sl - m : 0]] : 0u;
+          if (m & 1u) {
+            den ^= exl[(lm >= kLogZero ? kLongZero : lm) + e2];
+            e2 += x2;
+          }
         }
         OML[sl] = lg2[om];  // log 0 = 512 where this lane has no coefficient
-        const uint32_t xi = p ? kN - p : 0u;  // log X^-1
-        uint32_t x2 = 2 * xi;
-        x2 = umin32(x2, x2 - kN);
-        uint32_t num = 0, den = 0, e = 0;
 #pragma unroll 4
         for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1); coefficients beyond this frame's degree are zero
           const uint32_t l0 = OML[j];
           num ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
           e += xi;
-        }
-        e = 0;
-#pragma unroll 4
-        for (uint32_t m = 1; m <= dmax; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
-          const uint32_t l0 = CLL[m];
-          den ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
-          e += x2;
         }
         y = (mine && num && den) ? ex[lg[num] + kN - lg[den]] : 0u;
       }
@@ -1240,7 +1239,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   const size_t mask_bytes = up(static_cast<size_t>(chunks) * 8);
   const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws),
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws),
                             plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + roots_bytes + left_bytes + 256, stream));
   uint8_t *d_synd = ws + plane_bytes;
   uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);

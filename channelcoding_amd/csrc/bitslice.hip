@@ -471,7 +471,7 @@ int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d
   const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;
   const size_t plane_bytes = G64 * n * 32, eval_bytes = G64 * k * 32;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&ws), plane_bytes + eval_bytes, stream));
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws), plane_bytes + eval_bytes, stream));
   uint8_t *d_eval = ws + plane_bytes;
   const unsigned long long want = (G + 3) / 4, cap = static_cast<unsigned long long>(code->num_cus) * 32;
   const int grid = static_cast<int>(want < cap ? want : cap);

@@ -337,6 +337,22 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
   DeviceGuard guard(dev);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) code->num_cus = prop.multiProcessorCount;
+  {  // workspace pool of the handle (see cc_internal.hpp); without one the default pool serves
+    hipMemPoolProps pp = {};
+    pp.allocType = hipMemAllocationTypePinned;
+    pp.handleTypes = hipMemHandleTypeNone;
+    pp.location.type = hipMemLocationTypeDevice;
+    pp.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &pp) == hipSuccess) {
+      uint64_t keep = ~0ull;
+      if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess)
+        code->pool = pool;
+      else
+        (void)hipMemPoolDestroy(pool);
+    }
+    (void)hipGetLastError();
+  }
 
   if (code->soft) {
     MinSumGeometry &g = code->geo;
@@ -496,6 +512,7 @@ void cc_code_destroy(cc_code *code) {
     if (code->stage) host_stage_free(code->stage);
     if (code->d_wide) (void)hipFree(code->d_wide);
     if (code->d_alg) (void)hipFree(code->d_alg);
+    if (code->pool) (void)hipMemPoolDestroy(code->pool);  // (blocks of calls still in flight go back when they complete)
   }
   delete code;
 }
@@ -690,7 +707,7 @@ static int hard_dev(const cc_code *code, bool float_in, const void *d_in, const 
     return launch_pgz_erasures(code, static_cast<const uint8_t *>(d_in), d_er, d_off, d_out, d_nerr, d_status, B, stream);
   uint8_t *bytes = nullptr;
   const size_t count = B * code->tab.n;
-  CC_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&bytes), count + 16, stream));
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&bytes), count + 16, stream));
   hipLaunchKernelGGL(sign_bytes_kernel, dim3(code->num_cus * 8), dim3(256), 0, stream, static_cast<const float *>(d_in),
                      bytes, static_cast<unsigned long long>(count));
   const int rc = launch_pgz_erasures(code, bytes, d_er, d_off, d_out, d_nerr, d_status, B, stream);

@@ -89,12 +89,20 @@ struct cc_code {
   mutable ccamd::McWorkspace *mc = nullptr;  // lazily allocated Monte-Carlo chunk buffers
   mutable ccamd::HostStage *stage = nullptr;  // lazily allocated staging of the host-pointer entry points
   mutable std::mutex lazy_lock;               // guards the creation of the two above
+  // stream-ordered workspace of the multi-pass kernels (bit-plane RS path, large min-sum state, PGZ trials): a pool of
+  // the handle's own whose release threshold is "never", so that after the first call of a given size nothing is
+  // requested from or returned to the driver (the default pool trims at every synchronisation).  nullptr: default pool.
+  hipMemPool_t pool = nullptr;
   int num_cus = 256;
   bool force_generic = false;  // CC_AMD_FORCE_GENERIC=1: A/B the generic kernel against the fast one
   std::string name;
 };
 
 namespace ccamd {
+
+inline hipError_t workspace_alloc(const cc_code *code, void **p, size_t bytes, hipStream_t stream) {
+  return code->pool ? hipMallocFromPoolAsync(p, bytes, code->pool, stream) : hipMallocAsync(p, bytes, stream);
+}
 
 void set_last_error(const std::string &s);
 int hip_fail(hipError_t e, const char *what);

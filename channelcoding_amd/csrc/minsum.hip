@@ -317,7 +317,7 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   p.gstate = nullptr;
   p.gslab = lds / sizeof(float);
   if (gstate) {  // stream-ordered scratch: one slab per resident workgroup, freed behind the kernel
-    hipError_t ea = hipMallocAsync(reinterpret_cast<void **>(&p.gstate), lds * static_cast<size_t>(grid), stream);
+    hipError_t ea = workspace_alloc(code, reinterpret_cast<void **>(&p.gstate), lds * static_cast<size_t>(grid), stream);
     if (ea != hipSuccess) return hip_fail(ea, "hipMallocAsync(min-sum state)");
     lds = 0;
   }
