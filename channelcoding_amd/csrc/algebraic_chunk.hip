@@ -942,26 +942,32 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
                   unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, uint8_t *__restrict__ out,
                   int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   constexpr uint32_t kLongZero = 8448, kLongSize = 16640, kN = 255;
-  constexpr int kScratch = 224;  // per quarter: CSL u16[32] | CS u8[32] | CLL u16[34] | OML u16[16]
-  __shared__ __attribute__((aligned(16))) uint8_t smem[1792 + 16 * kScratch + kLongSize];
-  uint8_t *ex = smem;                                         // [1024]
-  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
-  uint8_t *lg = smem + 1536;                                  // [256] plain log table (log 0 = 0)
-  uint8_t *exl = smem + 1792 + 16 * kScratch;
+  // per quarter: CSL u16[16 + 32] (log S_j at index 16 + j; the 16 entries in front and those from 2t on stay "zero", so
+  // S_(j-m) needs no range test) | CS u8[32] | CLL u16[34] log lambda_m | CLZ u16[34] the same with the long table's
+  // zero marker | OMZ u16[16] log omega_j (long-table marker)
+  constexpr int kScratch = 320, kExSize = 1040;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kExSize + 768 + 16 * kScratch + kLongSize];
+  uint8_t *ex = smem;                                            // [1040]: alpha^i, zero from 511 on (512 + 512 included)
+  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + kExSize);  // [256]
+  uint8_t *lg = smem + kExSize + 512;                            // [256] plain log table (log 0 = 0)
+  uint8_t *exl = smem + kExSize + 768 + 16 * kScratch;
   for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kLongZero ? T->exp[i % 255u] : 0;
-  for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
+  for (int i = threadIdx.x; i < kExSize; i += 256) ex[i] = i < 511 ? T->exp[i] : 0;
   lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
   lg[threadIdx.x] = T->log[threadIdx.x];
-  __syncthreads();
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, sl = lane & 15;
   const int n = T->n, t2 = T->nroots, nc = t2 + 1;
   const bool is_rs = T->family == CC_FAMILY_RS;
-  uint8_t *base = smem + 1792 + (wid * 4 + q) * kScratch;
-  uint16_t *CSL = reinterpret_cast<uint16_t *>(base);
-  uint8_t *CS = base + 64;
-  uint16_t *CLL = reinterpret_cast<uint16_t *>(base + 96);
-  uint16_t *OML = reinterpret_cast<uint16_t *>(base + 168);
+  uint8_t *base = smem + kExSize + 768 + (wid * 4 + q) * kScratch;
+  uint16_t *CSLp = reinterpret_cast<uint16_t *>(base);
+  uint16_t *CSL = CSLp + 16;
+  uint8_t *CS = base + 96;
+  uint16_t *CLL = reinterpret_cast<uint16_t *>(base + 128);
+  uint16_t *CLZ = reinterpret_cast<uint16_t *>(base + 200);
+  uint16_t *OMZ = reinterpret_cast<uint16_t *>(base + 272);
+  for (int j = sl; j < 48; j += 16) CSLp[j] = static_cast<uint16_t>(kLogZero);
+  __syncthreads();
   const uint32_t r0 = T->roots_log[0];
   const uint32_t step = t2 > 1 ? (T->roots_log[1] + kN - r0) % kN : 0;
 
@@ -1029,7 +1035,10 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
       }
 #pragma unroll
       for (int h = 0; h < 3; ++h)
-        if (sl + 16 * h < nc) CLL[sl + 16 * h] = static_cast<uint16_t>(lv[h]);
+        if (sl + 16 * h < nc) {
+          CLL[sl + 16 * h] = static_cast<uint16_t>(lv[h]);
+          CLZ[sl + 16 * h] = static_cast<uint16_t>(lv[h] >= kLogZero ? kLongZero : lv[h]);
+        }
       const Four nxt = take4();
       if (nxt.fs[0] >= 0) request(nxt, md, sv, lv);
 
@@ -1110,23 +1119,22 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         x2 = umin32(x2, x2 - kN);
         uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j = sl < deg
         uint32_t num = 0, den = 0, e = 0, e2 = 0;
-        // one pass over the locator: the omega coefficient of this lane, and lambda'(X^-1) = sum_{m odd} lambda_m
-        // X^-(m-1) for this lane's error (the two look-up chains overlap)
+        // one pass over the locator: the omega coefficient of this lane (S_(sl-m) = 0 for m > sl by the padding,
+        // lambda_m = 0 beyond the frame's degree), and lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1) for this lane's error
 #pragma unroll 4
         for (uint32_t m = 0; m <= dmax; ++m) {
-          const bool in = mine && static_cast<uint32_t>(sl) >= m && m <= static_cast<uint32_t>(deg) && sl - m < static_cast<uint32_t>(t2);
-          const uint32_t lm = CLL[m <= static_cast<uint32_t>(t2) ? m : 0];
-          om ^= in ? ex[lm + CSL[in ? sl - m : 0]] : 0u;
+          om ^= ex[CLL[m] + CSL[sl - static_cast<int>(m)]];
           if (m & 1u) {
-            den ^= exl[(lm >= kLogZero ? kLongZero : lm) + e2];
+            den ^= exl[CLZ[m] + e2];
             e2 += x2;
           }
         }
-        OML[sl] = lg2[om];  // log 0 = 512 where this lane has no coefficient
+        om = mine ? om : 0u;  // omega = S lambda mod x^deg: no coefficient from deg on
+        const uint32_t ol = lg2[om];
+        OMZ[sl] = static_cast<uint16_t>(ol >= kLogZero ? kLongZero : ol);
 #pragma unroll 4
-        for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1); coefficients beyond this frame's degree are zero
-          const uint32_t l0 = OML[j];
-          num ^= exl[(l0 >= kLogZero ? kLongZero : l0) + e];
+        for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1)
+          num ^= exl[OMZ[j] + e];
           e += xi;
         }
         y = (mine && num && den) ? ex[lg[num] + kN - lg[den]] : 0u;
