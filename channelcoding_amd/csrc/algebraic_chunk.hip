@@ -24,6 +24,7 @@
 
 namespace ccamd {
 int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream);  // bitslice.hip
+int launch_bitslice_roots_transpose(const void *d_masks, void *d_rootsT, size_t B, hipStream_t stream);
 namespace {
 
 constexpr uint32_t kLogZero = 512;  // log of 0: ex[kLogZero + anything < 512] = 0
@@ -1173,6 +1174,132 @@ chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
   }
 }
 
+
+// The correction stage with ONE LANE PER FRAME (64 frames of a chunk per wavefront), everything of a frame in that
+// lane's registers: 16 syndrome logs, 17 locator logs, the 16 omega logs it computes, and its 255-bit root vector
+// (eight words of bitslice_roots_transpose_kernel's output).  The errors of a frame are taken one at a time off the
+// root words (lowest set bit); each costs the two Forney sums with compile-time coefficient indices and unwrapped
+// exponents on the long antilog table.  No cross-lane traffic at all; a trip of the error loop serves up to 64
+// frames.  Frames that need the general treatment -- locator longer than 16, or L != deg (the re-check has to be
+// evaluated) -- go to chunk_fix_kernel through `left`.
+__global__ void __launch_bounds__(256)
+chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
+                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
+                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ rootsT,
+                  unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, uint8_t *__restrict__ out,
+                  int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
+  // exl: alpha^i for i < kZ, zero from kZ on; kZ marks a zero operand (log of 0), kZ + kZ still inside the table
+  constexpr uint32_t kZ = 8448, kLongSize = 2 * kZ + 64, kN = 255;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256];
+  uint8_t *exl = smem;
+  uint16_t *lgz = reinterpret_cast<uint16_t *>(smem + kLongSize);  // [256] log, kZ for 0
+  uint8_t *lg = smem + kLongSize + 512;                            // [256] plain log table (log 0 = 0)
+  for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kZ ? T->exp[i % 255u] : 0;
+  lgz[threadIdx.x] = static_cast<uint16_t>(threadIdx.x ? T->log[threadIdx.x] : kZ);
+  lg[threadIdx.x] = T->log[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = lane;
+  const int n = T->n, t2 = T->nroots, nc = t2 + 1;
+  const bool is_rs = T->family == CC_FAMILY_RS;
+
+  const unsigned long long nchunks = (B + 63) / 64;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+    const unsigned long long first = chunk * 64, frame = first + f;
+    const unsigned long long smask = mask[chunk];
+    if (smask == 0) {
+      if (lane == 0) left[chunk] = 0;
+      continue;
+    }
+    const bool dirty = (smask >> lane) & 1ull;
+    const uint32_t md = dirty ? meta[frame] : 0u;
+    const int deg = md & 0xFF, len = md >> 8;
+    const bool general = dirty && (deg > 16 || len != deg);  // chunk_fix_kernel's business
+    const unsigned long long lmask = __ballot(general);
+    if (lane == 0) {
+      left[chunk] = lmask;
+      if (lmask) atomicAdd(nleft, 1u);
+    }
+    int status = CC_FRAME_OK;
+    if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;  // bounded-distance decoding
+    if (deg < 1) status = CC_FRAME_LOCATOR;                            // cyclic.h:145-147
+    const unsigned long long group = 2 * chunk + (f >> 5);
+    const int fi = f & 31, bit = 8 * (fi & 3) + (fi >> 2);
+    uint32_t R[8];  // bit j of R[k]: position 32 k + j is a root
+#pragma unroll
+    for (int k = 0; k < 8; ++k) R[k] = rootsT[(group * 8 + k) * 32 + bit];
+    R[7] &= 0x7FFFFFFFu;  // there is no position 255
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += __builtin_popcount(R[k]);
+    if (static_cast<int>(cnt) != deg) status = CC_FRAME_LOCATOR;  // cyclic.h:134-143
+    const bool live = dirty && !general;
+    const bool fixing = live && status == CC_FRAME_OK;
+    if (live) {
+      if (nerr_out) nerr_out[frame] = fixing ? static_cast<int>(cnt) : -1;
+      if (status_out) status_out[frame] = status;
+    }
+    if (__ballot(fixing) == 0) continue;  // wave-uniform
+
+    uint32_t ll[17], ol[16];  // log lambda_m, log omega_j (kZ for zero)
+    if (is_rs) {
+      uint32_t sl[16];  // log S_j, j < 16 (omega_j, j < deg <= 16, needs no more)
+      const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sl[j] = j < t2 ? sb[j * 2048] : 0u;
+#pragma unroll
+      for (int m = 0; m < 17; ++m) {
+        const uint32_t v = m < nc ? llg[(chunk * nc + m) * 64 + f] : kLogZero;
+        ll[m] = v >= kLogZero ? kZ : v;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sl[j] = lgz[sl[j]];
+      const uint32_t dmax = static_cast<uint32_t>(wave_umax(fixing ? static_cast<uint32_t>(deg) : 0u));
+      // omega_j = sum_{m <= j} lambda_m S_{j-m} for j < deg (S lambda mod x^deg)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        uint32_t om = 0;
+        if (static_cast<uint32_t>(j) < dmax) {  // wave-uniform
+#pragma unroll
+          for (int m = 0; m <= j; ++m) om ^= exl[ll[m] + sl[j - m]];
+        }
+        ol[j] = j < deg ? static_cast<uint32_t>(lgz[om]) : kZ;
+      }
+    }
+    // the errors, one at a time off the root words
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t w = fixing ? R[k] : 0u;
+      while (__any(w != 0)) {
+        const bool has = w != 0;
+        const uint32_t p = 32 * k + (has ? __builtin_ctz(w) : 0);
+        w &= w - 1;
+        uint32_t y = 1;  // bch.h:80-83
+        if (is_rs) {     // Forney, rs.h:41-78
+          const uint32_t xi = p ? kN - p : 0u;  // log X^-1
+          uint32_t x2 = 2 * xi;
+          x2 = umin32(x2, x2 - kN);
+          uint32_t num = 0, den = 0, e = 0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {  // omega(X^-1)
+            num ^= exl[ol[j] + e];
+            e += xi;
+          }
+          e = 0;
+#pragma unroll
+          for (int m = 1; m < 17; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+            den ^= exl[ll[m] + e];
+            e += x2;
+          }
+          y = (num && den) ? exl[lg[num] + kN - lg[den]] : 0u;
+        }
+        if (has && y) out[frame * n + p] ^= static_cast<uint8_t>(y);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
@@ -1248,7 +1375,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
   CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws),
-                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + roots_bytes + left_bytes + 256, stream));
+                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + 2 * roots_bytes + left_bytes + 256, stream));
   uint8_t *d_synd = ws + plane_bytes;
   uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);
   uint16_t *d_meta = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_llg) + llg_bytes);
@@ -1257,6 +1384,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   uint8_t *d_roots = d_lamp + lamp_bytes;
   unsigned long long *d_left = reinterpret_cast<unsigned long long *>(d_roots + roots_bytes);
   uint32_t *d_nleft = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_left) + left_bytes);
+  uint8_t *d_rootsT = reinterpret_cast<uint8_t *>(d_nleft) + 256;
   int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
   if (rc == CC_OK) {
     static const int dbg_stop = [] {
@@ -1296,7 +1424,21 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
       max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
       grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
       const bool four = dbg_stop == 0 && !no_fix4();
-      if (four) {  // locators of degree <= 16, four frames per wavefront; the rest goes on through d_left
+      static const bool lane_form = [] {  // CC_AMD_FIX_LANE=0: the four-frames-per-wavefront corrector instead
+        const char *v = std::getenv("CC_AMD_FIX_LANE");
+        return !(v && v[0] == '0');
+      }();
+      if (four && lane_form) {  // one lane per frame; the rest goes on through d_left
+        if (launch_bitslice_roots_transpose(d_roots, d_rootsT, B, stream) != CC_OK) e = hipErrorLaunchFailure;
+        if (e == hipSuccess) {
+          const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * 6;
+          const int lgrid = static_cast<int>(blocks_needed < lcap ? blocks_needed : lcap);
+          hipLaunchKernelGGL(chunk_fixl_kernel, dim3(lgrid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
+                             d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_out,
+                             d_nerr, d_status, Bq);
+          e = hipGetLastError();
+        }
+      } else if (four) {  // locators of degree <= 16, four frames per wavefront; the rest goes on through d_left
         hipLaunchKernelGGL(chunk_fix4_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
                            d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_roots), d_left, d_nleft, d_out,
                            d_nerr, d_status, Bq);

@@ -403,6 +403,34 @@ bitslice_chien_kernel(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks,
   }
 }
 
+// masks[group][256] (word = position, bit = frame in plane order) -> rootsT[group][8][32] (word = frame in plane order,
+// bit = position within the segment of 32): a 32 x 32 bit transpose per (group, segment), one lane each, so that the
+// lane-per-frame corrector reads the eight words of ITS frame
+__global__ void __launch_bounds__(256)
+bitslice_roots_transpose_kernel(const uint4 *__restrict__ masks, uint4 *__restrict__ rootsT, unsigned long long tasks) {
+  const unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x;  // group * 8 + segment
+  if (t >= tasks) return;
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint4 v = masks[t * 8 + i];
+    w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) {  // exchange bit `sh` of the word index with bit `sh` of the bit position
+    const uint32_t m = sh == 16 ? 0x0000FFFFu : sh == 8 ? 0x00FF00FFu : sh == 4 ? 0x0F0F0F0Fu : sh == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      if (k & sh) continue;
+      const uint32_t x = ((w[k] >> sh) ^ w[k + sh]) & m;
+      w[k + sh] ^= x;
+      w[k] ^= x << sh;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rootsT[t * 8 + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 }  // namespace
 
 bool bitslice_supported(const cc_code *code) {
@@ -454,6 +482,15 @@ int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream
                      static_cast<const uint4 *>(d_lamp), static_cast<uint2 *>(d_masks), G);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice chien kernel launch");
+  return CC_OK;
+}
+
+int launch_bitslice_roots_transpose(const void *d_masks, void *d_rootsT, size_t B, hipStream_t stream) {
+  const unsigned long long tasks = ((B + 31) / 32) * 8;
+  hipLaunchKernelGGL(bitslice_roots_transpose_kernel, dim3(static_cast<unsigned>((tasks + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const uint4 *>(d_masks), static_cast<uint4 *>(d_rootsT), tasks);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "bitslice roots transpose kernel launch");
   return CC_OK;
 }
 
