@@ -1275,6 +1275,7 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         const bool has = w != 0;
         const uint32_t p = 32 * k + (has ? __builtin_ctz(w) : 0);
         w &= w - 1;
+        const uint32_t sym = has ? out[frame * n + p] : 0u;  // requested before the error value is worked out
         uint32_t y = 1;  // bch.h:80-83
         if (is_rs) {     // Forney, rs.h:41-78
           const uint32_t xi = p ? kN - p : 0u;  // log X^-1
@@ -1294,7 +1295,8 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
           }
           y = (num && den) ? exl[lg[num] + kN - lg[den]] : 0u;
         }
-        if (has && y) out[frame * n + p] ^= static_cast<uint8_t>(y);
+        // (an atomic XOR on the surrounding dword instead of the load / store pair was measured slower: 942 vs 1024 M)
+        if (has && y) out[frame * n + p] = static_cast<uint8_t>(sym ^ y);
       }
     }
   }
