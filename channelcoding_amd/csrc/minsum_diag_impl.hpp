@@ -219,7 +219,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   // stride, the two frames of a 32-lane half interleaved on even / odd dwords (conflict-free, and the byte
   // offset of a slot differs from its CY offset by a per-lane constant: one address register per slot).
   constexpr int CY_BYTES = FPW * RC * 8, CN_BYTES = (FPW / 2) * RC * 8;
-  constexpr int WAVE_BYTES = CY_BYTES + CN_BYTES;
+  // SINGLE: the one iteration accumulates the new column sums in the (otherwise unused, zero) cs field of the CY cells:
+  // an edge costs one 8-byte read {cs', y} and one 4-byte write instead of two reads and a write, and without the CN
+  // area three workgroups fit a CU
+  constexpr int WAVE_BYTES = CY_BYTES + (SINGLE ? 0 : CN_BYTES);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int fl = lane / LPF, lam = lane & (LPF - 1);
   char *cy_base = smem + wid * WAVE_BYTES;
@@ -358,7 +361,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
   // first frame of every group: staged like all the others, then the one after it
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
+  for (int c = 0; c < CPL; ++c)
+    if constexpr (!SINGLE) *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
   if (active) {
     stage(frame);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,7 +376,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // reduced and scattered, so their latency hides behind the DPP chain and the read-modify-writes
     // (SCMS1 on a geometry that already fills the register file fetches a row's operands when the row starts:
     //  the bit words below take the 14 registers the prefetch would hold)
-    constexpr bool PREFETCH = !(BITS1 && K * D >= 160);
+    // (SINGLE: the cs' half of a cell is written by the row before, so a row's operands are fetched when it starts)
+    constexpr bool PREFETCH = !(BITS1 && K * D >= 160) && !SINGLE;
     float2 cyq[D];
     float2 carry_cy[NLK ? NLK : 1];  // the head's operands of the row before: the tail's operands of this row
     float carry_sum[NLK ? NLK : 1];  // the head's running column sum of the row before
@@ -495,6 +500,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         constexpr int d = DD;
         if constexpr (d < 2 * NLK && (d & 1) == 0 && i >= 1)
           cn[d] = carry_sum[d / 2];  // the head added to this column in row i - 1 and kept the sum
+        else if constexpr (SINGLE)
+          cn[d] = cyq[d].x;
         else
           cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
       });
@@ -536,6 +543,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         constexpr int d = DD;
         if constexpr (d < 2 * NLK && (d & 1) == 1 && i + 1 < K)
           carry_sum[d / 2] = sum[d];  // the tail of this link continues it in row i + 1
+        else if constexpr (SINGLE)
+          *reinterpret_cast<float *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
         else
           *reinterpret_cast<float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
       });
@@ -553,20 +562,31 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     auto stop_scan = [&](auto ORC) {
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const float cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
-        const float yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
+        float cnv, yc;
+        if constexpr (SINGLE) {
+          const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs', y}
+          cnv = cy.x;
+          yc = cy.y;
+        } else {
+          cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
+          yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
+        }
         bool bit = cnv + yc < 0.0f;  // L = cs + y :180-182, b = L < 0 codes.h:51
         if (c == CPL - 1) bit = bit && (lam + LPF * c < n);
         const uint32_t cb = bit ? cbits[lam + LPF * c] : 0u;
         if constexpr (decltype(ORC)::value) acc |= cb;
         else acc ^= cb;
-        // next iteration: cs := cs', cs' := 0
-        *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
-        *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
+        // next iteration: cs := cs', cs' := 0 (SINGLE: there is none, and cs' already sits in the cell)
+        if constexpr (!SINGLE) {
+          *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
+          *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
+        }
       }
     };
     bool ok;
-    if (p.stop_rule == CC_STOP_PUBLISHED) {
+    if (SINGLE && p.stop_rule == CC_STOP_AS_SHIPPED) {
+      ok = true;  // no test at all, and nothing to move
+    } else if (p.stop_rule == CC_STOP_PUBLISHED) {
       stop_scan(std::true_type{});
       ok = group_or<LPF>(acc) == 0;
     } else {
@@ -659,13 +679,22 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
   const bool single = p.stop_rule == CC_STOP_AS_SHIPPED || p.iterations == 1;
+  // the message-free kernel has no CN area (see SINGLE in the kernel) and few registers: LDS alone caps its occupancy
+  constexpr size_t rc_cols = static_cast<size_t>(LPF) * CPL + (PARTIAL ? 48 : (LPF == 8 && CPL == 8 ? 8 : 16));
+  const size_t lds_s = lds - 4 * (FPW / 2) * rc_cols * 8;
+  unsigned long long per_cu_s = (160 * 1024) / lds_s;
+  if (per_cu_s > 8) per_cu_s = 8;
+  const unsigned long long max_grid_s = static_cast<unsigned long long>(code->num_cus) * per_cu_s;
+  const int grid_s = static_cast<int>(blocks_needed < max_grid_s ? blocks_needed : max_grid_s);
 #define CC_LAUNCH_S(V, O, S)                                                                                       \
   {                                                                                                                \
+    const size_t lds_k = (S) ? lds_s : lds;                                                                        \
+    const int grid_k = (S) ? grid_s : grid;                                                                        \
     e = hipFuncSetAttribute(                                                                                       \
         reinterpret_cast<const void *>(&minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S, CHAIN>),      \
-        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_k));                                     \
     if (e == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S, CHAIN>), dim3(grid), dim3(256), lds, \
+      hipLaunchKernelGGL((minsum_diag_kernel<K, D, V, RB, LPF, CPL, O, PARTIAL, PG, S, CHAIN>), dim3(grid_k), dim3(256), lds_k, \
                          stream, p, code->d_diag, code->d_colbits, d_llr, d_er, d_er_off, d_hard, d_L, d_iters,    \
                          d_status, Bq);                                                                            \
   }
