@@ -82,3 +82,36 @@ def test_encode_by_interpolation(t):
         cw = code.encode_batch(msg)
         assert np.array_equal(cw, o.encode(msg)), frames
         assert np.array_equal(code.extract_batch(cw), msg)
+
+
+ALTERNATIVES = [{"CC_AMD_FIX_LANE": "0"}, {"CC_AMD_NO_FIX4": "1"}, {"CC_AMD_NO_BM_REG": "1"},
+                {"CC_AMD_FIX_LANE": "0", "CC_AMD_NO_BM_REG": "1"}]
+
+
+@pytest.mark.parametrize("env", ALTERNATIVES, ids=lambda e: "+".join(sorted(e)))
+def test_alternative_kernels_stay_exact(env):
+    """The kernels the default path has replaced stay selectable (four-frames-per-wavefront and one-frame-per-wavefront
+    correctors, Berlekamp-Massey through LDS); the switches are read once per process, so each runs in its own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from checkers import BCH, BM, PGZ, RS, Oracle\n"
+        "from test_gpu_algebraic import TAGS, check_against_oracle, corrupt\n"
+        "import channelcoding_amd as cc\n"
+        "rng = np.random.default_rng(4)\n"
+        "for fam, t, alg in ((RS, 16, BM), (RS, 8, PGZ), (BCH, 6, BM)):\n"
+        "    o = Oracle(fam, 8, t)\n"
+        "    code = (cc.primitive_bch if fam == BCH else cc.rs)(8, cc.errors(t), TAGS[alg]())\n"
+        "    hi = 2 if fam == BCH else 256\n"
+        "    for frames in (1, 65, 2200):\n"
+        "        cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))\n"
+        "        rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, t + 6))) for f in range(frames)])\n"
+        "        check_against_oracle(code.correct_batch(rx), o, alg, rx)\n"
+        "print('ALT OK')\n" % (here, os.path.dirname(here)))
+    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "ALT OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
