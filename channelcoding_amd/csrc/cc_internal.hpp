@@ -34,6 +34,15 @@ struct MinSumParams {
   const uint32_t *colmask;  // device
   float *gstate;            // generic kernel, state too large for LDS: per-workgroup slabs in HBM (else nullptr)
   unsigned long long gslab; // floats per workgroup slab
+  // Two-pass decoding (minsum_diag.hip: launch_two_pass), all zero otherwise.  ctl: device words [0] strategy (1 = two
+  // passes), [1] frames the first pass handed on, [2] frames of the sample that did not stop, [3] list overflow.
+  uint32_t *ctl = nullptr;
+  uint32_t *list = nullptr;   // frames handed on
+  unsigned list_cap = 0;
+  int gate = -1;              // 1: run only if ctl[0] == 1; 0: only if ctl[0] != 1; -1: always
+  int first_pass = 0;         // message-free kernel: 1 = a frame that does not stop is appended to list instead of
+                              // written; 2 = the same on a sample, counting into ctl[2] only
+  int b_from_ctl = 0;         // the batch size is ctl[1] (second pass over the compacted frames)
 };
 
 // device-resident tables of one code for the algebraic chain and the encoder

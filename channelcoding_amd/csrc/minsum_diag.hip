@@ -5,6 +5,7 @@
 #include "minsum_diag_impl.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ccamd {
 
@@ -227,11 +228,127 @@ size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
 }
 
 
+// ---------------- two-pass decoding ----------------
+// At high SNR almost every frame stops after its first iteration, which the message-free kernel runs at about half the
+// cost of the general one (no messages, one column-sum array) -- but only the device knows the operating point.  So:
+//   sample      message-free first pass over the first 8192 frames, counting the frames that did not stop
+//   decide      two passes if fewer than 1 in 8 of them did not
+//   first pass  (if two passes) message-free kernel over all frames: a frame that stops is written, the others are
+//               appended to a list
+//   second pass (if two passes) their channel values gathered into a compact batch, the general kernel over it from
+//               the first iteration on (same arithmetic, same results), results scattered back
+//   otherwise   the general kernel over all frames -- also if the list overflowed (more than B / 4 frames)
+// Everything is enqueued unconditionally; kernels on the branch not taken return at once (MinSumParams::gate).
+namespace {
+
+__global__ void twopass_decide_kernel(uint32_t *ctl, unsigned sample) { ctl[0] = (ctl[2] * 8u < sample) ? 1u : 0u; }
+__global__ void twopass_overflow_kernel(uint32_t *ctl, unsigned cap) {
+  if (ctl[0] == 1u && (ctl[3] != 0u || ctl[1] > cap)) ctl[0] = 2u;  // not 1: the general kernel takes the whole batch
+}
+__global__ void __launch_bounds__(256)
+twopass_gather_kernel(const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ list, const float *__restrict__ llr,
+                      float *__restrict__ llr2, int n) {
+  if (ctl[0] != 1u) return;
+  const unsigned long long cnt = ctl[1];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long k = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); k < cnt; k += nwaves) {
+    const float *src = llr + static_cast<unsigned long long>(list[k]) * n;
+    float *dst = llr2 + k * n;
+    for (int j = lane; j < n; j += 64) dst[j] = src[j];
+  }
+}
+__global__ void __launch_bounds__(256)
+twopass_scatter_kernel(const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ list, const uint8_t *__restrict__ hard2,
+                       const uint16_t *__restrict__ iters2, const int32_t *__restrict__ status2, uint8_t *__restrict__ hard,
+                       uint16_t *__restrict__ iters, int32_t *__restrict__ status, int n) {
+  if (ctl[0] != 1u) return;
+  const unsigned long long cnt = ctl[1];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long k = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); k < cnt; k += nwaves) {
+    const unsigned long long f = list[k];
+    for (int j = lane; j < n; j += 64) hard[f * n + j] = hard2[k * n + j];
+    if (lane == 0) {
+      if (iters) iters[f] = iters2[k];
+      if (status) status[f] = status2[k];
+    }
+  }
+}
+
+bool two_pass_enabled() {
+  static const bool v = [] {
+    const char *e = std::getenv("CC_AMD_TWO_PASS");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
+int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams &p, const float *d_llr, uint8_t *d_hard,
+                    uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
+  const size_t n = code->tab.n, cap = B / 4, sample = 8192;
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  const size_t o_list = 256, o_llr = o_list + up(cap * 4), o_hard = o_llr + up(cap * n * 4), o_it = o_hard + up(cap * n),
+               o_st = o_it + up(cap * 2), total = o_st + up(cap * 4);
+  uint8_t *ws = nullptr;
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws), total, stream));
+  uint32_t *ctl = reinterpret_cast<uint32_t *>(ws), *list = reinterpret_cast<uint32_t *>(ws + o_list);
+  float *llr2 = reinterpret_cast<float *>(ws + o_llr);
+  uint8_t *hard2 = ws + o_hard;
+  uint16_t *it2 = reinterpret_cast<uint16_t *>(ws + o_it);
+  int32_t *st2 = reinterpret_cast<int32_t *>(ws + o_st);
+  int rc = CC_OK;
+  hipError_t he = hipMemsetAsync(ctl, 0, 256, stream);
+  if (he != hipSuccess) rc = hip_fail(he, "two-pass control words");
+  MinSumParams q = p;
+  q.ctl = ctl;
+  q.list = list;
+  q.list_cap = static_cast<unsigned>(cap);
+  if (rc == CC_OK) {  // sample
+    q.first_pass = 2;
+    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
+  }
+  if (rc == CC_OK) {
+    hipLaunchKernelGGL(twopass_decide_kernel, dim3(1), dim3(1), 0, stream, ctl, static_cast<unsigned>(sample));
+    q.first_pass = 1;  // first pass over everything
+    q.gate = 1;
+    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
+  }
+  if (rc == CC_OK) {
+    hipLaunchKernelGGL(twopass_overflow_kernel, dim3(1), dim3(1), 0, stream, ctl, static_cast<unsigned>(cap));
+    const int grid = code->num_cus * 4;
+    hipLaunchKernelGGL(twopass_gather_kernel, dim3(grid), dim3(256), 0, stream, ctl, list, d_llr, llr2, static_cast<int>(n));
+    q.first_pass = 0;  // second pass: the general kernel over the compacted frames
+    q.b_from_ctl = 1;
+    rc = e->launch(code, q, llr2, nullptr, nullptr, hard2, nullptr, it2, st2, cap, stream);
+    if (rc == CC_OK)
+      hipLaunchKernelGGL(twopass_scatter_kernel, dim3(grid), dim3(256), 0, stream, ctl, list, hard2, it2, st2, d_hard,
+                         d_iters, d_status, static_cast<int>(n));
+  }
+  if (rc == CC_OK) {  // the other branch: one pass over everything
+    q.b_from_ctl = 0;
+    q.gate = 0;
+    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
+  }
+  if (rc == CC_OK) {
+    he = hipGetLastError();
+    if (he != hipSuccess) rc = hip_fail(he, "two-pass kernels launch");
+  }
+  (void)hipFreeAsync(ws, stream);
+  return rc;
+}
+
+}  // namespace
+
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                        size_t B, hipStream_t stream) {
   const DiagEntry *e = diag_entry(code->tab);
   if (!e) return CC_ERR_UNSUPPORTED;
+  const bool plain = p.variant == CC_ALG_MS || p.variant == CC_ALG_NMS || p.variant == CC_ALG_OMS || p.variant == CC_ALG_2DNMS;
+  if (two_pass_enabled() && plain && p.stop_rule != CC_STOP_AS_SHIPPED && p.iterations >= 2 && d_er_off == nullptr &&
+      d_L == nullptr && B >= (size_t(1) << 16))
+    return launch_two_pass(code, e, p, d_llr, d_hard, d_iters, d_status, B, stream);
   return e->launch(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 }
 

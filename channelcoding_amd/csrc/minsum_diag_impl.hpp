@@ -206,6 +206,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
                    uint8_t *__restrict__ hard, float *__restrict__ Lout, uint16_t *__restrict__ iters_out,
                    int32_t *__restrict__ status_out, unsigned long long B) {
   static_assert(K % RB == 0 && K <= 32, "row batching");
+  // two-pass decoding (cc_internal.hpp: MinSumParams): strategy gate and batch size decided on the device
+  if (p.gate == 1 && p.ctl[0] != 1u) return;
+  if (p.gate == 0 && p.ctl[0] == 1u) return;
+  if (p.b_from_ctl) B = p.ctl[1] < p.list_cap ? p.ctl[1] : p.list_cap;
   static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
   static_assert(2 * PG::NP <= D && !(PARTIAL && PG::NP > 0), "paired slots");
   static_assert(!CHAIN || PG::NP == 0 || (PG::gap(0) == 1 && PG::gap(PG::NP - 1) == 1), "links are gap-1 pairs");
@@ -604,7 +608,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       // column by column: result of the decided frame out of LDS, the next frame's channel value in, result to
       // HBM -- nothing is held in registers across columns.  The wait comes before the first store: the next frame
       // was staged a whole frame ago and nothing else of this wave is in flight, so it is free.
+      // first pass of two: a frame that has not stopped is handed on (nothing of it is written here)
+      const bool handed = SINGLE && p.first_pass != 0 && !ok;
       auto emit = [&](int c, float L) {
+        if (handed) return;
         if (c < CPL - 1 || lam + LPF * c < n) {
           hp[LPF * c] = (L < 0.0f) ? 1 : 0;
           if (Lp) Lp[LPF * c] = L;
@@ -638,8 +645,18 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         }
       }
       if (lam == 0) {
-        if (iters_out) iters_out[done] = static_cast<uint16_t>(done_it);
-        if (status_out) status_out[done] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
+        if (handed) {
+          if (p.first_pass == 2) {
+            atomicAdd(&p.ctl[2], 1u);
+          } else {
+            const uint32_t at = atomicAdd(&p.ctl[1], 1u);
+            if (at < p.list_cap) p.list[at] = static_cast<uint32_t>(done);
+            else p.ctl[3] = 1u;
+          }
+        } else {
+          if (iters_out) iters_out[done] = static_cast<uint16_t>(done_it);
+          if (status_out) status_out[done] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
+        }
       }
       if (active) stage(frame + ngroups);  // after the reads of STG above have been consumed
     } else {
@@ -678,7 +695,7 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
   hipError_t e = hipSuccess;
-  const bool single = p.stop_rule == CC_STOP_AS_SHIPPED || p.iterations == 1;
+  const bool single = p.stop_rule == CC_STOP_AS_SHIPPED || p.iterations == 1 || p.first_pass != 0;
   // the message-free kernel has no CN area (see SINGLE in the kernel) and few registers: LDS alone caps its occupancy
   constexpr size_t rc_cols = static_cast<size_t>(LPF) * CPL + (PARTIAL ? 48 : (LPF == 8 && CPL == 8 ? 8 : 16));
   const size_t lds_s = lds - 4 * (FPW / 2) * rc_cols * 8;
