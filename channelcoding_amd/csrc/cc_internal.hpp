@@ -34,16 +34,31 @@ struct MinSumParams {
   const uint32_t *colmask;  // device
   float *gstate;            // generic kernel, state too large for LDS: per-workgroup slabs in HBM (else nullptr)
   unsigned long long gslab; // floats per workgroup slab
-  // Two-pass decoding (minsum_diag.hip: launch_two_pass), all zero otherwise.  ctl: device words [0] strategy (1 = two
-  // passes), [1] frames the first pass handed on, [2] frames of the sample that did not stop, [3] list overflow.
+  // Two-pass decoding (minsum_diag.hip: launch_two_pass), all zero otherwise.  ctl: device words [1] frames the first
+  // pass handed on, [2] frames of the sample that did not stop, [3] list overflow.  The device's choice: two passes iff
+  // ctl[2] * 8 < sample (first pass), and its result is used iff the list did not overflow either (everything after it).
   uint32_t *ctl = nullptr;
+  unsigned sample = 0;
   uint32_t *list = nullptr;   // frames handed on
   unsigned list_cap = 0;
-  int gate = -1;              // 1: run only if ctl[0] == 1; 0: only if ctl[0] != 1; -1: always
+  int gate = -1;              // 1: run only if the sample says "two passes"; -1: always
   int first_pass = 0;         // message-free kernel: 1 = a frame that does not stop is appended to list instead of
                               // written; 2 = the same on a sample, counting into ctl[2] only
-  int b_from_ctl = 0;         // the batch size is ctl[1] (second pass over the compacted frames)
+  // general kernel, launched ONCE per call: if two passes are in effect it decodes the compacted batch (these buffers,
+  // ctl[1] frames) instead of the caller's -- one launch per call, whichever branch the device took
+  int dual = 0;
+  const float *llr2 = nullptr;
+  uint8_t *hard2 = nullptr;
+  uint16_t *iters2 = nullptr;
+  int32_t *status2 = nullptr;
 };
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool two_pass_sampled(const MinSumParams &p) { return p.ctl[2] * 8u < p.sample; }
+__device__ __forceinline__ bool two_pass_in_effect(const uint32_t *ctl, unsigned sample, unsigned cap) {
+  return ctl[2] * 8u < sample && ctl[3] == 0u && ctl[1] <= cap;
+}
+#endif
 
 // device-resident tables of one code for the algebraic chain and the encoder
 struct AlgebraicTables {

@@ -231,24 +231,21 @@ size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
 // ---------------- two-pass decoding ----------------
 // At high SNR almost every frame stops after its first iteration, which the message-free kernel runs at about half the
 // cost of the general one (no messages, one column-sum array) -- but only the device knows the operating point.  So:
-//   sample      message-free first pass over the first 8192 frames, counting the frames that did not stop
-//   decide      two passes if fewer than 1 in 8 of them did not
+//   sample      message-free first pass over the first 4096 frames, counting the frames that did not stop;
+//               two passes if fewer than 1 in 8 of them did not
 //   first pass  (if two passes) message-free kernel over all frames: a frame that stops is written, the others are
 //               appended to a list
 //   second pass (if two passes) their channel values gathered into a compact batch, the general kernel over it from
 //               the first iteration on (same arithmetic, same results), results scattered back
 //   otherwise   the general kernel over all frames -- also if the list overflowed (more than B / 4 frames)
-// Everything is enqueued unconditionally; kernels on the branch not taken return at once (MinSumParams::gate).
+// Everything is enqueued unconditionally; the helper kernels of the branch not taken return at once
+// (MinSumParams::gate), and the general kernel is launched once and picks its batch on the device (MinSumParams::dual).
 namespace {
 
-__global__ void twopass_decide_kernel(uint32_t *ctl, unsigned sample) { ctl[0] = (ctl[2] * 8u < sample) ? 1u : 0u; }
-__global__ void twopass_overflow_kernel(uint32_t *ctl, unsigned cap) {
-  if (ctl[0] == 1u && (ctl[3] != 0u || ctl[1] > cap)) ctl[0] = 2u;  // not 1: the general kernel takes the whole batch
-}
 __global__ void __launch_bounds__(256)
-twopass_gather_kernel(const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ list, const float *__restrict__ llr,
-                      float *__restrict__ llr2, int n) {
-  if (ctl[0] != 1u) return;
+twopass_gather_kernel(const uint32_t *__restrict__ ctl, unsigned sample, unsigned cap, const uint32_t *__restrict__ list,
+                      const float *__restrict__ llr, float *__restrict__ llr2, int n) {
+  if (!two_pass_in_effect(ctl, sample, cap)) return;
   const unsigned long long cnt = ctl[1];
   const int lane = threadIdx.x & 63;
   const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
@@ -259,10 +256,11 @@ twopass_gather_kernel(const uint32_t *__restrict__ ctl, const uint32_t *__restri
   }
 }
 __global__ void __launch_bounds__(256)
-twopass_scatter_kernel(const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ list, const uint8_t *__restrict__ hard2,
-                       const uint16_t *__restrict__ iters2, const int32_t *__restrict__ status2, uint8_t *__restrict__ hard,
-                       uint16_t *__restrict__ iters, int32_t *__restrict__ status, int n) {
-  if (ctl[0] != 1u) return;
+twopass_scatter_kernel(const uint32_t *__restrict__ ctl, unsigned sample, unsigned cap, const uint32_t *__restrict__ list,
+                       const uint8_t *__restrict__ hard2, const uint16_t *__restrict__ iters2,
+                       const int32_t *__restrict__ status2, uint8_t *__restrict__ hard, uint16_t *__restrict__ iters,
+                       int32_t *__restrict__ status, int n) {
+  if (!two_pass_in_effect(ctl, sample, cap)) return;
   const unsigned long long cnt = ctl[1];
   const int lane = threadIdx.x & 63;
   const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
@@ -286,7 +284,7 @@ bool two_pass_enabled() {
 
 int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams &p, const float *d_llr, uint8_t *d_hard,
                     uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
-  const size_t n = code->tab.n, cap = B / 4, sample = 8192;
+  const size_t n = code->tab.n, cap = B / 4, sample = 4096;
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   const size_t o_list = 256, o_llr = o_list + up(cap * 4), o_hard = o_llr + up(cap * n * 4), o_it = o_hard + up(cap * n),
                o_st = o_it + up(cap * 2), total = o_st + up(cap * 4);
@@ -304,31 +302,33 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   q.ctl = ctl;
   q.list = list;
   q.list_cap = static_cast<unsigned>(cap);
+  q.sample = static_cast<unsigned>(sample);
   if (rc == CC_OK) {  // sample
     q.first_pass = 2;
     rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
   }
   if (rc == CC_OK) {
-    hipLaunchKernelGGL(twopass_decide_kernel, dim3(1), dim3(1), 0, stream, ctl, static_cast<unsigned>(sample));
-    q.first_pass = 1;  // first pass over everything
+    q.first_pass = 1;  // first pass over everything (returns at once unless the sample says so)
     q.gate = 1;
     rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
   }
   if (rc == CC_OK) {
-    hipLaunchKernelGGL(twopass_overflow_kernel, dim3(1), dim3(1), 0, stream, ctl, static_cast<unsigned>(cap));
     const int grid = code->num_cus * 4;
-    hipLaunchKernelGGL(twopass_gather_kernel, dim3(grid), dim3(256), 0, stream, ctl, list, d_llr, llr2, static_cast<int>(n));
-    q.first_pass = 0;  // second pass: the general kernel over the compacted frames
-    q.b_from_ctl = 1;
-    rc = e->launch(code, q, llr2, nullptr, nullptr, hard2, nullptr, it2, st2, cap, stream);
-    if (rc == CC_OK)
-      hipLaunchKernelGGL(twopass_scatter_kernel, dim3(grid), dim3(256), 0, stream, ctl, list, hard2, it2, st2, d_hard,
-                         d_iters, d_status, static_cast<int>(n));
-  }
-  if (rc == CC_OK) {  // the other branch: one pass over everything
-    q.b_from_ctl = 0;
-    q.gate = 0;
+    const unsigned su = static_cast<unsigned>(sample), cu = static_cast<unsigned>(cap);
+    hipLaunchKernelGGL(twopass_gather_kernel, dim3(grid), dim3(256), 0, stream, ctl, su, cu, list, d_llr, llr2,
+                       static_cast<int>(n));
+    // the general kernel, once: over the compacted frames if the device chose two passes, over everything otherwise
+    q.first_pass = 0;
+    q.gate = -1;
+    q.dual = 1;
+    q.llr2 = llr2;
+    q.hard2 = hard2;
+    q.iters2 = it2;
+    q.status2 = st2;
     rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
+    if (rc == CC_OK)
+      hipLaunchKernelGGL(twopass_scatter_kernel, dim3(grid), dim3(256), 0, stream, ctl, su, cu, list, hard2, it2, st2,
+                         d_hard, d_iters, d_status, static_cast<int>(n));
   }
   if (rc == CC_OK) {
     he = hipGetLastError();

@@ -207,9 +207,15 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
                    int32_t *__restrict__ status_out, unsigned long long B) {
   static_assert(K % RB == 0 && K <= 32, "row batching");
   // two-pass decoding (cc_internal.hpp: MinSumParams): strategy gate and batch size decided on the device
-  if (p.gate == 1 && p.ctl[0] != 1u) return;
-  if (p.gate == 0 && p.ctl[0] == 1u) return;
-  if (p.b_from_ctl) B = p.ctl[1] < p.list_cap ? p.ctl[1] : p.list_cap;
+  if (p.gate == 1 && !two_pass_sampled(p)) return;
+  if (p.dual && two_pass_in_effect(p.ctl, p.sample, p.list_cap)) {  // second pass: the compacted frames
+    llr = p.llr2;
+    hard = p.hard2;
+    Lout = nullptr;
+    iters_out = p.iters2;
+    status_out = p.status2;
+    B = p.ctl[1] < p.list_cap ? p.ctl[1] : p.list_cap;
+  }
   static_assert(LPF == 8 || LPF == 16, "a frame occupies half or all of a 16-lane DPP row");
   static_assert(2 * PG::NP <= D && !(PARTIAL && PG::NP > 0), "paired slots");
   static_assert(!CHAIN || PG::NP == 0 || (PG::gap(0) == 1 && PG::gap(PG::NP - 1) == 1), "links are gap-1 pairs");
