@@ -302,7 +302,13 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   q.ctl = ctl;
   q.list = list;
   q.list_cap = static_cast<unsigned>(cap);
-  q.sample = static_cast<unsigned>(sample);
+  // two passes iff fewer than 1 in `den` frames of the sample did not stop (the device tests ctl[2] * 8 < q.sample)
+  static const unsigned den = [] {
+    const char *v = std::getenv("CC_AMD_TWO_PASS_DEN");
+    const int d = v ? std::atoi(v) : 0;
+    return d >= 1 ? static_cast<unsigned>(d) : 8u;
+  }();
+  q.sample = static_cast<unsigned>(sample * 8 / den);
   if (rc == CC_OK) {  // sample
     q.first_pass = 2;
     rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
@@ -314,7 +320,7 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   }
   if (rc == CC_OK) {
     const int grid = code->num_cus * 4;
-    const unsigned su = static_cast<unsigned>(sample), cu = static_cast<unsigned>(cap);
+    const unsigned su = q.sample, cu = q.list_cap;  // the same test in every kernel
     hipLaunchKernelGGL(twopass_gather_kernel, dim3(grid), dim3(256), 0, stream, ctl, su, cu, list, d_llr, llr2,
                        static_cast<int>(n));
     // the general kernel, once: over the compacted frames if the device chose two passes, over everything otherwise
