@@ -352,8 +352,11 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
   const DiagEntry *e = diag_entry(code->tab);
   if (!e) return CC_ERR_UNSUPPORTED;
   const bool plain = p.variant == CC_ALG_MS || p.variant == CC_ALG_NMS || p.variant == CC_ALG_OMS || p.variant == CC_ALG_2DNMS;
+  // the helper launches cost ~0.06 ms per call: only where a call runs for a millisecond or more (frames x edges per
+  // iteration; 1.5e9 = 2^18 frames of BCH(255,231), never BCH(63,45) at 2^20)
+  const double work = static_cast<double>(B) * code->tab.n * code->tab.k;
   if (two_pass_enabled() && plain && p.stop_rule != CC_STOP_AS_SHIPPED && p.iterations >= 2 && d_er_off == nullptr &&
-      d_L == nullptr && B >= (size_t(1) << 16))
+      d_L == nullptr && work >= 1.5e9)
     return launch_two_pass(code, e, p, d_llr, d_hard, d_iters, d_status, B, stream);
   return e->launch(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 }

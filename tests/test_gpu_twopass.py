@@ -15,7 +15,15 @@ import channelcoding_amd as cc
 
 pytestmark = pytest.mark.gpu
 
-FRAMES = (1 << 16) + 777  # the launcher takes the two-pass route from 2^16 frames on
+FRAMES = (1 << 18) + 777  # the launcher takes the two-pass route from 1.5e9 frame-edges on (2^18 frames of this code)
+
+
+def decode_on_device(code, y):
+    """Device-pointer entry point with the whole batch in one call (host buffers are cut into 32 MiB chunks, which
+    never reach the two-pass route)."""
+    import torch
+    r = code.correct_batch(torch.from_numpy(y).cuda())
+    return {k: v.cpu().numpy() for k, v in r.items()}
 
 
 def batch(kind, n, rate):
@@ -37,7 +45,7 @@ def test_two_pass_matches_oracle(kind, variant, rule):
     tag = cc.min_sum_tag(20) if variant == "ms" else cc.normalized_min_sum_tag(20, 0.8)
     code = cc.primitive_bch(8, cc.errors(3), tag, stop_rule=rule)
     y = batch(kind, o.n, o.l / o.n)
-    res = code.correct_batch(y)
+    res = decode_on_device(code, y)
     # the oracle on a sample that contains every kind of frame: the first 300, and 300 that ran longest on the device
     pick = np.unique(np.concatenate([np.arange(300), np.argsort(res["iters"])[-300:], np.flatnonzero(res["status"])[:100]]))
     ob, _, oit, ost = o.minsum(0 if variant == "ms" else 1, 20, y[pick], 0.8 if variant == "nms" else 1.0, 0.0, rule,
@@ -62,11 +70,11 @@ def test_two_pass_equals_one_pass(tmp_path):
     script = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import numpy as np\n"
-        "from test_gpu_twopass import batch\n"
+        "from test_gpu_twopass import batch, decode_on_device\n"
         "import channelcoding_amd as cc\n"
         "code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20))\n"
         "for kind in ('high', 'trap'):\n"
-        "    r = code.correct_batch(batch(kind, 255, 231 / 255))\n"
+        "    r = decode_on_device(code, batch(kind, 255, 231 / 255))\n"
         "    np.savez(sys.argv[1] + kind, out=r['out'], iters=r['iters'], status=r['status'])\n"
         % (here, os.path.dirname(here)))
     for mode in ("1", "0"):
