@@ -86,3 +86,24 @@ def test_two_pass_equals_one_pass(tmp_path):
         b = np.load(tmp_path / ("m0_" + kind + ".npz"))
         for key in ("out", "iters", "status"):
             assert np.array_equal(a[key], b[key]), (kind, key)
+
+
+def test_monte_carlo_counters_do_not_depend_on_the_route():
+    """cc_mc_run_dev at 8 dB (chunks of 2^20 frames: the two-pass route) against CC_AMD_TWO_PASS=0: same noise (keyed by
+    the global frame index), so every counter -- frames, word / bit errors, failures, iteration histogram -- must agree."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import channelcoding_amd as cc\n"
+        "from channelcoding_amd.montecarlo import DeviceBackend\n"
+        "be = DeviceBackend(cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20)), random_codewords=False)\n"
+        "print('COUNTERS', [int(x) for x in be.run(8.0, 1234, 0, 1 << 21)])\n" % os.path.dirname(here))
+    seen = []
+    for mode in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, CC_AMD_TWO_PASS=mode), capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        seen.append([ln for ln in out.stdout.splitlines() if ln.startswith("COUNTERS")][-1])
+    assert seen[0] == seen[1]
+    counters = eval(seen[0].split(" ", 1)[1])
+    assert counters[0] == 1 << 21 and 0 < counters[1] < counters[0] // 100  # frames; a few word errors at 8 dB
