@@ -11,7 +11,7 @@ from channelcoding_amd.montecarlo import DeviceBackend
 code = cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20))
 for rc in (False, True):
     be = DeviceBackend(code, random_codewords=rc)
-    for ebno in (2.0, 4.0, 6.0):
+    for ebno in (2.0, 4.0, 6.0, 8.0):
         frames = 1 << 22
         be.run(ebno, 0, 0, 1 << 16)
         torch.cuda.synchronize()
