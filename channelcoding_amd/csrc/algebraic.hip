@@ -424,10 +424,14 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
+#ifdef CC_AMD_EXPERIMENTS  // phase timing (profiles/tools/rs_bench.py); the product library always runs the whole chain
   static const int dbg_stop = [] {
     const char *e = std::getenv("CC_AMD_ALG_STOP");
     return e ? std::atoi(e) : 0;
   }();
+#else
+  const int dbg_stop = 0;
+#endif
   const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
   if (float_in)
     hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg, d_in,

@@ -439,7 +439,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
                 uint4 *__restrict__ lamp, uint32_t *__restrict__ nleft,
                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;  // chunks chunk_fix4_kernel will hand on (it runs after this kernel)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;  // chunks chunk_fixl_kernel will hand on (it runs after this kernel)
   uint8_t *ex = smem;                                         // [1024]
   uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + 1024);  // [256]
   for (int i = threadIdx.x; i < 1024; i += 256) ex[i] = i < 512 ? T->exp[i] : 0;
@@ -727,7 +727,7 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
                  const uint32_t *__restrict__ nleft, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
                  int32_t *__restrict__ status_out, unsigned long long B) {
-  if (nleft && *nleft == 0) return;  // nothing was handed on by chunk_fix4_kernel (the usual case)
+  if (nleft && *nleft == 0) return;  // nothing was handed on by chunk_fixl_kernel (the usual case)
   // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
   // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
   constexpr uint32_t kLongZero = 8448, kLongSize = 16640;
@@ -930,251 +930,6 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
 }
 
 
-// The same stage with FOUR dirty frames per wavefront, 16 lanes each, for locators of degree <= 16 whose roots the
-// Chien kernel has already marked: what is left per frame is fixed work (operands in, root positions out of the bit
-// masks, Forney with one lane per error, status out), and chunk_fix_kernel pays it once per wavefront per frame.
-// A frame's 255-bit root vector comes from four ballots over the mask words of its group (bit = frame); lane e of a
-// quarter takes the e-th set bit as its error position.  Frames with a longer locator (never correctable within the
-// capability) are handed to chunk_fix_kernel through `left`.
-__global__ void __launch_bounds__(256)
-chunk_fix4_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
-                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
-                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
-                  unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, uint8_t *__restrict__ out,
-                  int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
-  constexpr uint32_t kLongZero = 8448, kLongSize = 16640, kN = 255;
-  // per quarter: CSL u16[16 + 32] (log S_j at index 16 + j; the 16 entries in front and those from 2t on stay "zero", so
-  // S_(j-m) needs no range test) | CS u8[32] | CLL u16[34] log lambda_m | CLZ u16[34] the same with the long table's
-  // zero marker | OMZ u16[16] log omega_j (long-table marker)
-  constexpr int kScratch = 320, kExSize = 1040;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[kExSize + 768 + 16 * kScratch + kLongSize];
-  uint8_t *ex = smem;                                            // [1040]: alpha^i, zero from 511 on (512 + 512 included)
-  uint16_t *lg2 = reinterpret_cast<uint16_t *>(smem + kExSize);  // [256]
-  uint8_t *lg = smem + kExSize + 512;                            // [256] plain log table (log 0 = 0)
-  uint8_t *exl = smem + kExSize + 768 + 16 * kScratch;
-  for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kLongZero ? T->exp[i % 255u] : 0;
-  for (int i = threadIdx.x; i < kExSize; i += 256) ex[i] = i < 511 ? T->exp[i] : 0;
-  lg2[threadIdx.x] = threadIdx.x ? T->log[threadIdx.x] : kLogZero;
-  lg[threadIdx.x] = T->log[threadIdx.x];
-  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, sl = lane & 15;
-  const int n = T->n, t2 = T->nroots, nc = t2 + 1;
-  const bool is_rs = T->family == CC_FAMILY_RS;
-  uint8_t *base = smem + kExSize + 768 + (wid * 4 + q) * kScratch;
-  uint16_t *CSLp = reinterpret_cast<uint16_t *>(base);
-  uint16_t *CSL = CSLp + 16;
-  uint8_t *CS = base + 96;
-  uint16_t *CLL = reinterpret_cast<uint16_t *>(base + 128);
-  uint16_t *CLZ = reinterpret_cast<uint16_t *>(base + 200);
-  uint16_t *OMZ = reinterpret_cast<uint16_t *>(base + 272);
-  for (int j = sl; j < 48; j += 16) CSLp[j] = static_cast<uint16_t>(kLogZero);
-  __syncthreads();
-  const uint32_t r0 = T->roots_log[0];
-  const uint32_t step = t2 > 1 ? (T->roots_log[1] + kN - r0) % kN : 0;
-
-  const unsigned long long nchunks = (B + 63) / 64;
-  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
-  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
-  for (unsigned long long chunk = wave; chunk < nchunks; chunk += nwaves) {
-    const unsigned long long first = chunk * 64;
-    unsigned long long todo = mask[chunk], leftover = 0;
-    if (todo == 0) {
-      if (lane == 0) left[chunk] = 0;
-      continue;
-    }
-    uint32_t rw[2][4];  // root masks of the chunk's two groups: word p of a group, bit 8 (f & 3) + (f >> 2) = frame f
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) rw[h][c] = roots[(2 * chunk + h) * 256 + lane + 64 * c];
-    // The operands of the NEXT four frames (deg / L, two syndromes and up to three locator coefficients per lane) are
-    // requested before the current four are worked on: their HBM / L2 latency is off the dependent chain.
-    struct Four {
-      int fs[4];
-    };
-    auto take4 = [&]() {
-      Four s;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        s.fs[k] = todo ? __builtin_ctzll(todo) : -1;
-        todo &= todo - 1;
-      }
-      return s;
-    };
-    auto mine_of = [&](const Four &s) {
-      const int fq = q == 0 ? s.fs[0] : q == 1 ? s.fs[1] : q == 2 ? s.fs[2] : s.fs[3];
-      return fq >= 0 ? fq : s.fs[0];  // idle quarters shadow the first frame and store nothing
-    };
-    auto request = [&](const Four &s, uint32_t &md, uint32_t (&sv)[2], uint32_t (&lv)[3]) {
-      const int fc = mine_of(s);
-      md = meta[first + fc];
-      const unsigned long long group = 2 * chunk + (fc >> 5);
-      const int fi = fc & 31;
-      const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) sv[h] = sl + 16 * h < t2 ? sb[(sl + 16 * h) * 2048] : 0u;
-#pragma unroll
-      for (int h = 0; h < 3; ++h) lv[h] = sl + 16 * h < nc ? llg[(chunk * nc + sl + 16 * h) * 64 + fc] : 0u;
-    };
-    Four cur = take4();
-    uint32_t md = 0, sv[2] = {0, 0}, lv[3] = {0, 0, 0};
-    request(cur, md, sv, lv);
-    while (cur.fs[0] >= 0) {
-      const int(&fs)[4] = cur.fs;
-      const int fq = q == 0 ? fs[0] : q == 1 ? fs[1] : q == 2 ? fs[2] : fs[3];
-      const bool act = fq >= 0;
-      const int fc = act ? fq : fs[0];
-      const unsigned long long frame = first + fc;
-      const int deg = md & 0xFF, len = md >> 8;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j = sl + 16 * h;
-        if (j < t2) {
-          CS[j] = static_cast<uint8_t>(sv[h]);
-          CSL[j] = lg2[sv[h]];
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 3; ++h)
-        if (sl + 16 * h < nc) {
-          CLL[sl + 16 * h] = static_cast<uint16_t>(lv[h]);
-          CLZ[sl + 16 * h] = static_cast<uint16_t>(lv[h] >= kLogZero ? kLongZero : lv[h]);
-        }
-      const Four nxt = take4();
-      if (nxt.fs[0] >= 0) request(nxt, md, sv, lv);
-
-      // the four frames' root vectors: bit p of R = "position p is a root"
-      uint32_t R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int fk = fs[k] >= 0 ? fs[k] : fs[0], fik = fk & 31, bit = 8 * (fik & 3) + (fik >> 2);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t w = (fk >> 5) ? rw[1][c] : rw[0][c];
-          const unsigned long long b64 = __ballot((w >> bit) & 1u);
-          if (q == k) {
-            R[2 * c] = static_cast<uint32_t>(b64);
-            R[2 * c + 1] = static_cast<uint32_t>(b64 >> 32);
-          }
-        }
-      }
-      R[7] &= 0x7FFFFFFFu;  // there is no position 255
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) cnt += __builtin_popcount(R[i]);
-
-      const bool longer = deg > 16;  // searched and corrected by chunk_fix_kernel
-      {
-        const unsigned long long lm = __ballot(act && longer && sl == 0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((lm >> (16 * k)) & 1ull) leftover |= 1ull << fs[k];
-      }
-      int status = CC_FRAME_OK;
-      // the PGZ tag runs as bounded-distance decoding: locator degree within capability
-      if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
-      if (deg < 1) status = CC_FRAME_LOCATOR;                          // cyclic.h:145-147
-      const int nerr = static_cast<int>(cnt);
-      if (nerr != deg) status = CC_FRAME_LOCATOR;                      // cyclic.h:134-143
-      const bool live = act && !longer;
-      bool mine = live && status == CC_FRAME_OK && sl < deg;           // this lane owns the sl-th error
-
-      // position of the sl-th root (ascending, the order of cyclic::zeroes)
-      uint32_t p = 0;
-      {
-        uint32_t rem = sl, wsel = 0, word = 0;
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t c = __builtin_popcount(R[i]);
-          if (!found && rem < c) {
-            found = true;
-            word = i;
-            wsel = R[i];
-          }
-          if (!found) rem -= c;
-        }
-        mine = mine && found;
-        if (!mine) rem = 0;
-        for (; rem != 0; --rem) wsel &= wsel - 1;
-        p = 32 * word + (wsel ? __builtin_ctz(wsel) : 0);
-      }
-      uint32_t sym = 0;
-      if (mine) sym = out[frame * n + p];  // needed after the error value
-
-      // error values: bch.h:80-83 (all ones) / Forney for rs.h:41-78
-      uint32_t y = mine ? 1u : 0u;
-      const uint32_t dmax = [&] {  // longest locator among the four (wave-uniform)
-        const uint32_t dv = (live && status == CC_FRAME_OK) ? static_cast<uint32_t>(deg) : 0u;
-        uint32_t mx = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t d = __builtin_amdgcn_readlane(dv, 16 * k);
-          mx = d > mx ? d : mx;
-        }
-        return mx;
-      }();
-      if (is_rs && dmax != 0) {
-        const uint32_t xi = p ? kN - p : 0u;  // log X^-1
-        uint32_t x2 = 2 * xi;
-        x2 = umin32(x2, x2 - kN);
-        uint32_t om = 0;  // omega_j = sum_{m<=j} S_{j-m} lambda_m, j = sl < deg
-        uint32_t num = 0, den = 0, e = 0, e2 = 0;
-        // one pass over the locator: the omega coefficient of this lane (S_(sl-m) = 0 for m > sl by the padding,
-        // lambda_m = 0 beyond the frame's degree), and lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1) for this lane's error
-#pragma unroll 4
-        for (uint32_t m = 0; m <= dmax; ++m) {
-          om ^= ex[CLL[m] + CSL[sl - static_cast<int>(m)]];
-          if (m & 1u) {
-            den ^= exl[CLZ[m] + e2];
-            e2 += x2;
-          }
-        }
-        om = mine ? om : 0u;  // omega = S lambda mod x^deg: no coefficient from deg on
-        const uint32_t ol = lg2[om];
-        OMZ[sl] = static_cast<uint16_t>(ol >= kLogZero ? kLongZero : ol);
-#pragma unroll 4
-        for (uint32_t j = 0; j < dmax; ++j) {  // omega(X^-1)
-          num ^= exl[OMZ[j] + e];
-          e += xi;
-        }
-        y = (mine && num && den) ? ex[lg[num] + kN - lg[den]] : 0u;
-      }
-      // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip), evaluated otherwise
-      if (__ballot(live && status == CC_FRAME_OK && len != deg) != 0) {
-        const uint32_t ly = lg[y];
-        uint32_t ev = (r0 * p) % kN;
-        const uint32_t dp = (step * p) % kN;
-        uint32_t mismatch = 0;
-        for (int j = 0; j < t2; ++j) {
-          uint32_t term = (mine && y) ? ex[ly + ev] : 0u;
-          ev += dp;
-          ev = ev >= kN ? ev - kN : ev;
-          term = dpp_xor<0xB1, 0xF>(term);
-          term = dpp_xor<0x4E, 0xF>(term);
-          term = dpp_xor<0x141, 0xF>(term);
-          term = dpp_xor<0x140, 0xF>(term);  // the sum over the 16 lanes of the quarter, in every lane
-          mismatch |= term ^ CS[j];
-        }
-        if (status == CC_FRAME_OK && len != deg && mismatch != 0) status = CC_FRAME_RECHECK;
-      }
-      const bool ok = status == CC_FRAME_OK;
-      if (mine && ok && y) out[frame * n + p] = static_cast<uint8_t>(sym ^ y);
-      if (live && sl == 0) {
-        if (nerr_out) nerr_out[frame] = ok ? nerr : -1;
-        if (status_out) status_out[frame] = status;
-      }
-      __builtin_amdgcn_wave_barrier();  // the scratch arrays are reused by the next four frames
-      cur = nxt;
-    }
-    if (lane == 0) {
-      left[chunk] = leftover;
-      if (leftover) atomicAdd(nleft, 1u);
-    }
-  }
-}
-
-
 // The correction stage with ONE LANE PER FRAME (64 frames of a chunk per wavefront), everything of a frame in that
 // lane's registers: 16 syndrome logs, 17 locator logs, the 16 omega logs it computes, and its 255-bit root vector
 // (eight words of bitslice_roots_transpose_kernel's output).  The errors of a frame are taken one at a time off the
@@ -1317,6 +1072,20 @@ bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
   return code->desc.algorithm == CC_ALG_BM || code->desc.algorithm == CC_ALG_PGZ;
 }
 
+// CC_AMD_ALG_STOP=1|2|3 (builds with -DCC_AMD_EXPERIMENTS only): stop the chain after syndromes / Berlekamp-Massey /
+// root search -- phase timing for profiles/tools/rs_bench.py; the product library always runs the whole chain
+static int alg_stop_stage() {
+#ifdef CC_AMD_EXPERIMENTS
+  static const int v = [] {
+    const char *e = std::getenv("CC_AMD_ALG_STOP");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+#else
+  return 0;
+#endif
+}
+
 template <int FPW>
 static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
                             int32_t *d_status, size_t B, hipStream_t stream) {
@@ -1330,11 +1099,7 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
   const unsigned long long Bq = B;
-  static const int dbg_stop = [] {
-    const char *e = std::getenv("CC_AMD_ALG_STOP");
-    return e ? std::atoi(e) : 0;
-  }();
-  const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
+  const int alg_arg = code->desc.algorithm | (alg_stop_stage() << 8);
   hipError_t e = hipSuccess;
   if (float_in) {
     if (lds > 48 * 1024)
@@ -1354,14 +1119,6 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "algebraic chunk kernel launch");
   return CC_OK;
-}
-
-static bool no_fix4() {  // experiments / cross-check: CC_AMD_NO_FIX4=1 sends every dirty frame through chunk_fix_kernel
-  static const bool v = [] {
-    const char *e = std::getenv("CC_AMD_NO_FIX4");
-    return e && e[0] == '1';
-  }();
-  return v;
 }
 
 // syndromes on bit planes (bitslice.hip), Berlekamp-Massey over chunks of 64 frames, root search on planes, corrections
@@ -1389,10 +1146,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   uint8_t *d_rootsT = reinterpret_cast<uint8_t *>(d_nleft) + 256;
   int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
   if (rc == CC_OK) {
-    static const int dbg_stop = [] {
-      const char *e = std::getenv("CC_AMD_ALG_STOP");
-      return e ? std::atoi(e) : 0;
-    }();
+    const int dbg_stop = alg_stop_stage();
     const unsigned long long Bq = B, blocks_needed = (chunks + 3) / 4;
     const size_t lds = 1536 + 4 * static_cast<size_t>(bm_layout(t2).bytes);
     unsigned long long per_cu = (160 * 1024) / lds;
@@ -1403,17 +1157,13 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
     if (lds > 48 * 1024)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chunk_bm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds));
-    static const bool no_reg = [] {
-      const char *v = std::getenv("CC_AMD_NO_BM_REG");
-      return v && v[0] == '1';
-    }();
     if (e == hipSuccess) {
       const unsigned long long reg_cap = static_cast<unsigned long long>(code->num_cus) * 3;
       const int reg_grid = static_cast<int>(blocks_needed < reg_cap ? blocks_needed : reg_cap);
-      if (t2 == 32 && !no_reg)
+      if (t2 == 32)
         hipLaunchKernelGGL((chunk_bm_reg_kernel<32>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
                            d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
-      else if (t2 == 16 && !no_reg)
+      else if (t2 == 16)
         hipLaunchKernelGGL((chunk_bm_reg_kernel<16>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
                            d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       else
@@ -1425,12 +1175,8 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
     if (e == hipSuccess) {
       max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
       grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
-      const bool four = dbg_stop == 0 && !no_fix4();
-      static const bool lane_form = [] {  // CC_AMD_FIX_LANE=0: the four-frames-per-wavefront corrector instead
-        const char *v = std::getenv("CC_AMD_FIX_LANE");
-        return !(v && v[0] == '0');
-      }();
-      if (four && lane_form) {  // one lane per frame; the rest goes on through d_left
+      const bool four = dbg_stop == 0;
+      if (four) {  // one lane per frame; what it cannot settle goes on through d_left
         if (launch_bitslice_roots_transpose(d_roots, d_rootsT, B, stream) != CC_OK) e = hipErrorLaunchFailure;
         if (e == hipSuccess) {
           const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * 6;
@@ -1440,11 +1186,6 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
                              d_nerr, d_status, Bq);
           e = hipGetLastError();
         }
-      } else if (four) {  // locators of degree <= 16, four frames per wavefront; the rest goes on through d_left
-        hipLaunchKernelGGL(chunk_fix4_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
-                           d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_roots), d_left, d_nleft, d_out,
-                           d_nerr, d_status, Bq);
-        e = hipGetLastError();
       }
       if (e == hipSuccess) {
         hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
@@ -1464,12 +1205,6 @@ int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in,
                            int32_t *d_status, size_t B, hipStream_t stream) {
   if (B == 0) return CC_OK;
   if (bitslice_supported(code)) return launch_chunk_bitsliced(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
-  static const int fpw = [] {
-    const char *e = std::getenv("CC_AMD_CHUNK_FPW");
-    return e ? std::atoi(e) : 32;
-  }();
-  if (fpw == 16) return launch_chunk_fpw<16>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
-  if (fpw == 64) return launch_chunk_fpw<64>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
   return launch_chunk_fpw<32>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
 }
 

@@ -442,10 +442,9 @@ bool bitslice_supported(const cc_code *code) {
   const CodeTables &t = code->tab;
   if (t.q != 8 || t.n != 255 || code->field->poly != kPoly) return false;
   const size_t t2 = t.roots.size();
-  static const size_t min_t2 = [] {  // experiments: CC_AMD_BITSLICE_MIN_T2
-    const char *e = std::getenv("CC_AMD_BITSLICE_MIN_T2");
-    return e ? static_cast<size_t>(std::atoi(e)) : size_t(8);
-  }();
+  // with fewer than 8 syndromes the fixed passes over the batch cost more than the table arithmetic they replace
+  // (profiles/r02_experiments.md, E10)
+  constexpr size_t min_t2 = 8;
   if (t2 < min_t2 || t2 > 32 || t.root_powers.size() != t2) return false;
   for (size_t j = 0; j < t2; ++j)
     if (t.root_powers[j] != j + 1) return false;

@@ -3,12 +3,16 @@
 // API (see include/channelcoding_amd.h for the file:line map).  Host-pointer
 // entry points stage through device memory and call the _dev ones; there is no
 // CPU decode path in this library.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "cc_internal.hpp"
@@ -45,6 +49,79 @@ struct DeviceGuard {
 // chunk k + 1 overlaps the kernel and the download of chunk k -- and waits for ITS streams only
 // (hipStreamSynchronize, never hipDeviceSynchronize: other streams of the caller keep running).  Calls on one
 // handle are serialised by `lock`; different handles are independent.
+// Copies between pageable caller memory and the page-locked staging ring are plain memcpy calls spread over a few
+// worker threads (one thread moves ~10 GB/s, the DMA engine 55 GB/s; round 2 handed pageable pointers to
+// hipMemcpyAsync, which then blocks the calling thread until the data has moved and with it the pipeline:
+// profiles/r02_host_path.txt, 49 ms for what upload and kernel together should do in 31).  Process-wide, created on
+// first use, never joined (the workers touch no HIP state and sleep on a condition variable).
+class CopyPool {
+ public:
+  static CopyPool &get() {
+    static CopyPool *pool = new CopyPool();
+    return *pool;
+  }
+  void copy(void *dst, const void *src, size_t bytes) {
+    const size_t piece = 4u << 20;
+    if (bytes <= piece || workers_ == 0) {
+      std::memcpy(dst, src, bytes);
+      return;
+    }
+    const size_t parts = std::min<size_t>((bytes + piece - 1) / piece, static_cast<size_t>(workers_) + 1);
+    const size_t each = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
+    std::atomic<int> left{0};
+    std::mutex dm;
+    std::condition_variable dcv;
+    size_t off = each;  // the caller's own share is [0, each)
+    {
+      std::lock_guard<std::mutex> g(m_);
+      for (; off < bytes; off += each) {
+        const size_t len = std::min(each, bytes - off);
+        ++left;
+        jobs_.push_back(Job{static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len, &left, &dm, &dcv});
+      }
+    }
+    cv_.notify_all();
+    std::memcpy(dst, src, std::min(each, bytes));
+    std::unique_lock<std::mutex> lk(dm);
+    dcv.wait(lk, [&] { return left.load() == 0; });
+  }
+
+ private:
+  struct Job {
+    char *dst;
+    const char *src;
+    size_t len;
+    std::atomic<int> *left;
+    std::mutex *dm;
+    std::condition_variable *dcv;
+  };
+  CopyPool() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    workers_ = hc >= 16 ? 7 : hc >= 8 ? 5 : hc >= 4 ? 2 : 0;  // 3 / 7 / 15 workers: 35 / 33 / 32 ms per 2^20 frames at 4 dB
+    for (int i = 0; i < workers_; ++i) std::thread([this] { run(); }).detach();
+  }
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !jobs_.empty(); });
+        j = jobs_.back();
+        jobs_.pop_back();
+      }
+      std::memcpy(j.dst, j.src, j.len);
+      {
+        std::lock_guard<std::mutex> g(*j.dm);  // the waiter cannot leave (and destroy dm / dcv) between the two lines
+        if (j.left->fetch_sub(1) == 1) j.dcv->notify_one();
+      }
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<Job> jobs_;
+  int workers_ = 0;
+};
+
 struct HostStage {
   std::mutex lock;
   hipStream_t stream[2] = {nullptr, nullptr};
@@ -53,10 +130,32 @@ struct HostStage {
     size_t cap = 0;
   };
   Buf buf[2][8];
+  Buf pin[2][8];  // page-locked twins of buf for pageable caller memory (same slot / index)
+  struct Pending {
+    void *dst;
+    const void *src;
+    size_t bytes;
+  };
+  std::vector<Pending> pending[2];  // results waiting in pin[slot][*] for their stream to finish
   int init() {
     for (hipStream_t &s : stream)
       if (!s) CC_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return CC_OK;
+  }
+  // A call of several chunks starts on a fresh pair of streams.  Measured (profiles/r03_host_path.txt,
+  // profiles/tools/host_path_trace.py): once a stream pair has been through a call whose chunks were fed from the host
+  // side with gaps (pageable caller memory), every later call on that pair runs its copies and kernels one after the
+  // other -- 46 ms for 2^20 frames at 4 dB where the same call on new streams takes 25 -- for the rest of the process;
+  // rocprofv3's copy trace shows the transfers of the fast case on the DMA engines next to the kernels.  Creating two
+  // streams costs ~40 us, so calls of one or two chunks (below ~64 MiB) keep the pair they have.
+  int fresh_streams() {
+    for (hipStream_t &s : stream)
+      if (s) {
+        CC_HIP_TRY(hipStreamSynchronize(s));
+        CC_HIP_TRY(hipStreamDestroy(s));
+        s = nullptr;
+      }
+    return init();
   }
   template <typename T>
   int get(int slot, int idx, size_t count, T **out) {  // grow-only; contents are not preserved
@@ -74,10 +173,66 @@ struct HostStage {
     *out = static_cast<T *>(b.p);
     return CC_OK;
   }
-  int drain() {
-    for (hipStream_t s : stream)
-      if (s) CC_HIP_TRY(hipStreamSynchronize(s));
+  int get_pinned(int slot, int idx, size_t bytes, void **out) {
+    Buf &b = pin[slot][idx];
+    if (bytes > b.cap) {
+      if (b.p) (void)hipHostFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      const size_t want = bytes + bytes / 4;
+      CC_HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+      b.cap = want;
+    }
+    *out = b.p;
     return CC_OK;
+  }
+  // is the caller's buffer something the DMA engines reach directly (page-locked / registered / device memory)?
+  static bool dma_ready(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+      (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error of ours
+      return false;
+    }
+    return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+  }
+  // host -> device on the slot's stream; `direct` = dma_ready(h_src base), decided once per call
+  int upload(int slot, int idx, void *d_dst, const void *h_src, size_t bytes, bool direct) {
+    if (bytes == 0) return CC_OK;
+    if (!direct) {
+      void *ring = nullptr;
+      if (int rc = get_pinned(slot, idx, bytes, &ring)) return rc;
+      CopyPool::get().copy(ring, h_src, bytes);
+      h_src = ring;
+    }
+    CC_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, stream[slot]));
+    return CC_OK;
+  }
+  // device -> host behind the slot's kernels; a pageable destination receives its bytes in retire()
+  int download(int slot, int idx, void *h_dst, const void *d_src, size_t bytes, bool direct) {
+    if (bytes == 0) return CC_OK;
+    if (direct) {
+      CC_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, stream[slot]));
+      return CC_OK;
+    }
+    void *ring = nullptr;
+    if (int rc = get_pinned(slot, idx, bytes, &ring)) return rc;
+    CC_HIP_TRY(hipMemcpyAsync(ring, d_src, bytes, hipMemcpyDeviceToHost, stream[slot]));
+    pending[slot].push_back(Pending{h_dst, ring, bytes});
+    return CC_OK;
+  }
+  // wait for everything enqueued on the slot and hand its staged results to the caller's buffers
+  int retire(int slot) {
+    if (!stream[slot]) return CC_OK;
+    const hipError_t e = hipStreamSynchronize(stream[slot]);
+    if (e == hipSuccess)
+      for (const Pending &q : pending[slot]) CopyPool::get().copy(q.dst, q.src, q.bytes);
+    pending[slot].clear();
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize (host staging)");
+    return CC_OK;
+  }
+  int drain() {
+    const int a = retire(0), b = retire(1);
+    return a != CC_OK ? a : b;
   }
 };
 void host_stage_free(HostStage *st) {
@@ -86,6 +241,8 @@ void host_stage_free(HostStage *st) {
     if (st->stream[slot]) (void)hipStreamSynchronize(st->stream[slot]);
     for (HostStage::Buf &b : st->buf[slot])
       if (b.p) (void)hipFree(b.p);
+    for (HostStage::Buf &b : st->pin[slot])
+      if (b.p) (void)hipHostFree(b.p);
     if (st->stream[slot]) (void)hipStreamDestroy(st->stream[slot]);
   }
   delete st;
@@ -105,6 +262,11 @@ struct StageLock {
     }
     held = std::unique_lock<std::mutex>(st->lock);
     rc = st->init();
+  }
+  // every way out of a host-pointer call, error paths included, leaves nothing in flight that still writes to the
+  // caller's buffers or reads the staging buffers (a second wait on idle streams costs microseconds)
+  ~StageLock() {
+    if (st && held.owns_lock()) (void)st->drain();
   }
 };
 // frames per chunk: about 32 MiB of the widest per-frame stream, at least 16 frames
@@ -386,17 +548,6 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
       CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_colbits), cb.size() * sizeof(uint32_t)));
       CC_HIP_TRY(hipMemcpy(code->d_colbits, cb.data(), cb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (g.W == 64 && code->custom_H.empty()) {
-      std::vector<uint64_t> em(static_cast<size_t>(t.k) * g.C, 0ull);
-      for (unsigned i = 0; i < t.k; ++i)
-        for (int c = 0; c < g.C; ++c)
-          for (unsigned lane = 0; lane < 64; ++lane) {
-            const unsigned j = lane + 64u * static_cast<unsigned>(c);
-            if (j < t.n && i <= j && t.row0[j - i]) em[i * g.C + c] |= 1ull << lane;
-          }
-      CC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&code->d_emask), em.size() * sizeof(uint64_t)));
-      CC_HIP_TRY(hipMemcpy(code->d_emask, em.data(), em.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    }
   }
   if (matrix_only) {
     *out = code.release();
@@ -504,7 +655,6 @@ void cc_code_destroy(cc_code *code) {
   if (code->device != CC_DEVICE_NONE) {
     DeviceGuard guard(code->device);
     if (code->d_colmask) (void)hipFree(code->d_colmask);
-    if (code->d_emask) (void)hipFree(code->d_emask);
     if (code->d_diag) (void)hipFree(code->d_diag);
     if (code->d_colbits) (void)hipFree(code->d_colbits);
     if (code->d_parity) (void)hipFree(code->d_parity);
@@ -611,12 +761,18 @@ int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t 
   if (sl.rc != CC_OK) return sl.rc;
   HostStage &st = *sl.st;
   const size_t CH = chunk_frames(n * sizeof(float), B);
+  if (B > 2 * CH)
+    if (int rc_fs = st.fresh_streams()) return rc_fs;
+  // pageable caller memory goes through the page-locked ring (HostStage::upload / download); buffers the DMA engines
+  // reach themselves (hipHostMalloc, hipHostRegister) are used in place
+  const bool dma_in = HostStage::dma_ready(llr), dma_out = HostStage::dma_ready(hard),
+             dma_it = iters && HostStage::dma_ready(iters), dma_st = status && HostStage::dma_ready(status);
   size_t k = 0;
   for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
     const int slot = static_cast<int>(k & 1);
     const size_t m = B - c0 < CH ? B - c0 : CH;
     hipStream_t s = st.stream[slot];
-    CC_HIP_TRY(hipStreamSynchronize(s));  // the chunk that used this slot's buffers two turns ago is home
+    if (int rc = st.retire(slot)) return rc;  // the chunk that used this slot's buffers two turns ago is home
     float *d_llr = nullptr, *d_L = nullptr;
     uint8_t *d_hard = nullptr;
     uint16_t *d_iters = nullptr;
@@ -629,13 +785,16 @@ int cc_correct_soft_batch(const cc_code *code, const float *llr, const uint16_t 
     if (int rc = st.get(slot, 3, m, &d_status)) return rc;
     if (L)
       if (int rc = st.get(slot, 4, m * n, &d_L)) return rc;
-    CC_HIP_TRY(hipMemcpyAsync(d_llr, llr + c0 * n, m * n * sizeof(float), hipMemcpyHostToDevice, s));
+    if (int rc = st.upload(slot, 0, d_llr, llr + c0 * n, m * n * sizeof(float), dma_in)) return rc;
     if (int rc = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return rc;
     if (int rc = launch_minsum(code, d_llr, d_er, d_off, d_hard, d_L, d_iters, d_status, m, s)) return rc;
-    CC_HIP_TRY(hipMemcpyAsync(hard + c0 * n, d_hard, m * n, hipMemcpyDeviceToHost, s));
-    if (L) CC_HIP_TRY(hipMemcpyAsync(L + c0 * n, d_L, m * n * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (iters) CC_HIP_TRY(hipMemcpyAsync(iters + c0, d_iters, m * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
-    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (int rc = st.download(slot, 1, hard + c0 * n, d_hard, m * n, dma_out)) return rc;
+    if (L)
+      if (int rc = st.download(slot, 4, L + c0 * n, d_L, m * n * sizeof(float), HostStage::dma_ready(L))) return rc;
+    if (iters)
+      if (int rc = st.download(slot, 2, iters + c0, d_iters, m * sizeof(uint16_t), dma_it)) return rc;
+    if (status)
+      if (int rc = st.download(slot, 3, status + c0, d_status, m * sizeof(int32_t), dma_st)) return rc;
   }
   return st.drain();
 }
@@ -752,12 +911,16 @@ static int hard_host(const cc_code *code, bool float_in, const void *in, const u
   HostStage &st = *sl.st;
   const size_t esz = float_in ? sizeof(float) : 1;
   const size_t CH = chunk_frames(n * esz, B);
+  if (B > 2 * CH)
+    if (int rc_fs = st.fresh_streams()) return rc_fs;
+  const bool dma_in = HostStage::dma_ready(in), dma_out = HostStage::dma_ready(out),
+             dma_ne = nerr && HostStage::dma_ready(nerr), dma_st = status && HostStage::dma_ready(status);
   size_t k = 0;
   for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
     const int slot = static_cast<int>(k & 1);
     const size_t m = B - c0 < CH ? B - c0 : CH;
     hipStream_t s = st.stream[slot];
-    CC_HIP_TRY(hipStreamSynchronize(s));
+    if (int r = st.retire(slot)) return r;
     uint8_t *d_in = nullptr, *d_out = nullptr;
     int32_t *d_nerr = nullptr, *d_status = nullptr;
     const uint16_t *d_er = nullptr;
@@ -766,12 +929,14 @@ static int hard_host(const cc_code *code, bool float_in, const void *in, const u
     if (int r = st.get(slot, 1, m * n, &d_out)) return r;
     if (int r = st.get(slot, 2, m, &d_nerr)) return r;
     if (int r = st.get(slot, 3, m, &d_status)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(d_in, static_cast<const uint8_t *>(in) + c0 * n * esz, m * n * esz, hipMemcpyHostToDevice, s));
+    if (int r = st.upload(slot, 0, d_in, static_cast<const uint8_t *>(in) + c0 * n * esz, m * n * esz, dma_in)) return r;
     if (int r = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return r;
     if (int r = hard_dev(code, float_in, d_in, d_er, d_off, d_out, d_nerr, d_status, m, s)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(out + c0 * n, d_out, m * n, hipMemcpyDeviceToHost, s));
-    if (nerr) CC_HIP_TRY(hipMemcpyAsync(nerr + c0, d_nerr, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (int r = st.download(slot, 1, out + c0 * n, d_out, m * n, dma_out)) return r;
+    if (nerr)
+      if (int r = st.download(slot, 2, nerr + c0, d_nerr, m * sizeof(int32_t), dma_ne)) return r;
+    if (status)
+      if (int r = st.download(slot, 3, status + c0, d_status, m * sizeof(int32_t), dma_st)) return r;
   }
   return st.drain();
 }
@@ -824,19 +989,22 @@ static int byte_map_host(const cc_code *code, bool encode, const uint8_t *src, u
   if (sl.rc != CC_OK) return sl.rc;
   HostStage &st = *sl.st;
   const size_t CH = chunk_frames(n, B);
+  if (B > 2 * CH)
+    if (int rc_fs = st.fresh_streams()) return rc_fs;
+  const bool dma_in = HostStage::dma_ready(src), dma_out = HostStage::dma_ready(dst);
   size_t k = 0;
   for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
     const int slot = static_cast<int>(k & 1);
     const size_t m = B - c0 < CH ? B - c0 : CH;
     hipStream_t s = st.stream[slot];
-    CC_HIP_TRY(hipStreamSynchronize(s));
+    if (int r = st.retire(slot)) return r;
     uint8_t *d_src = nullptr, *d_dst = nullptr;
     if (int r = st.get(slot, 0, m * in_w, &d_src)) return r;
     if (int r = st.get(slot, 1, m * out_w, &d_dst)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(d_src, src + c0 * in_w, m * in_w, hipMemcpyHostToDevice, s));
+    if (int r = st.upload(slot, 0, d_src, src + c0 * in_w, m * in_w, dma_in)) return r;
     const int rc = encode ? launch_encode(code, d_src, d_dst, m, s) : launch_extract(code, d_src, d_dst, m, s);
     if (rc != CC_OK) return rc;
-    CC_HIP_TRY(hipMemcpyAsync(dst + c0 * out_w, d_dst, m * out_w, hipMemcpyDeviceToHost, s));
+    if (int r = st.download(slot, 1, dst + c0 * out_w, d_dst, m * out_w, dma_out)) return r;
   }
   return st.drain();
 }
@@ -892,6 +1060,31 @@ int cc_decode_soft_batch(const cc_code *code, const float *y, const uint16_t *er
 
 /* ------------------------------ q = 9 .. 15: 16-bit symbols (wide.hip) ------------------------------ */
 
+// lane-count limits of wide_correct_kernel (wide.hip), the same as the byte path's hard_supported: one lane per
+// coefficient of x^2t (Euklid), of S(x) u(x) (Euklid with erasures, degree < 2t + erasures <= 4t) and of the erasure
+// locator (Berlekamp-Massey pre-load, degree <= 2t)
+static int wide_hard_supported(const cc_code *code, bool erasures) {
+  const size_t t2 = code->tab.roots.size();
+  if (code->desc.algorithm == CC_ALG_EUKLID && (t2 > 63 || (erasures && t2 > 32))) {
+    set_last_error("the Euklid tag on the device handles t <= 31 (t <= 16 with erasures)");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (erasures && t2 > 63) {
+    set_last_error("erasure decoding on the device handles t <= 31 (one lane per coefficient of the erasure locator)");
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (erasures && code->desc.algorithm == CC_ALG_PGZ && code->tab.family == CC_FAMILY_RS) {
+    set_last_error("The PGZ-Algorithm does not support erasure decoding");  // hard_decision.h:66-68
+    return CC_ERR_UNSUPPORTED;
+  }
+  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
+    // capability gap: for BCH the reference runs the two-trial rule of bch.h:97-149, which the byte
+    // path implements (launch_pgz_erasures) and the 16-bit path does not
+    set_last_error("PGZ with erasures on 16-bit symbols is not supported (use the BM or Euklid tag)");
+    return CC_ERR_UNSUPPORTED;
+  }
+  return CC_OK;
+}
 static int wide_ready(const cc_code *code) {
   if (!code->wide) {
     set_last_error("the _u16 entry points serve GF(2^q) with q > 8; this handle has byte symbols");
@@ -921,10 +1114,7 @@ int cc_correct_hard_batch_u16_dev(const cc_code *code, const uint16_t *d_in, con
   if (!code || (B && (!d_in || !d_out))) return CC_ERR_INVALID_ARGUMENT;
   if ((d_erasures == nullptr) != (d_erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
   if (int rc = wide_ready(code)) return rc;
-  if (d_erasures && code->desc.algorithm == CC_ALG_PGZ) {
-    set_last_error("PGZ with erasures on 16-bit symbols is not supported");  // (RS: the reference throws, hard_decision.h:66-68)
-    return CC_ERR_UNSUPPORTED;
-  }
+  if (int rc = wide_hard_supported(code, d_erasures != nullptr)) return rc;
   DeviceGuard guard(code->device);
   return launch_wide_correct(code, d_in, d_erasures, d_erasure_offsets, d_out, d_nerr, d_status, B,
                              static_cast<hipStream_t>(stream));
@@ -945,19 +1135,22 @@ static int wide_map_host(const cc_code *code, int kind, const uint16_t *src, uin
   if (sl.rc != CC_OK) return sl.rc;
   HostStage &st = *sl.st;
   const size_t CH = chunk_frames(n * 2, B);
+  if (B > 2 * CH)
+    if (int rc_fs = st.fresh_streams()) return rc_fs;
+  const bool dma_in = HostStage::dma_ready(src), dma_out = HostStage::dma_ready(dst);
   size_t k = 0;
   for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
     const int slot = static_cast<int>(k & 1);
     const size_t m = B - c0 < CH ? B - c0 : CH;
     hipStream_t s = st.stream[slot];
-    CC_HIP_TRY(hipStreamSynchronize(s));
+    if (int r = st.retire(slot)) return r;
     uint16_t *d_src = nullptr, *d_dst = nullptr;
     if (int r = st.get(slot, 0, m * in_w, &d_src)) return r;
     if (int r = st.get(slot, 1, m * out_w, &d_dst)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(d_src, src + c0 * in_w, m * in_w * 2, hipMemcpyHostToDevice, s));
+    if (int r = st.upload(slot, 0, d_src, src + c0 * in_w, m * in_w * 2, dma_in)) return r;
     const int rc = kind == 0 ? launch_wide_encode(code, d_src, d_dst, m, s) : launch_wide_extract(code, d_src, d_dst, m, s);
     if (rc != CC_OK) return rc;
-    CC_HIP_TRY(hipMemcpyAsync(dst + c0 * out_w, d_dst, m * out_w * 2, hipMemcpyDeviceToHost, s));
+    if (int r = st.download(slot, 1, dst + c0 * out_w, d_dst, m * out_w * 2, dma_out)) return r;
   }
   return st.drain();
 }
@@ -975,10 +1168,7 @@ int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in, const uin
   if (!code || (B && (!in || !out))) return CC_ERR_INVALID_ARGUMENT;
   if ((erasures == nullptr) != (erasure_offsets == nullptr)) return CC_ERR_INVALID_ARGUMENT;
   if (int rc = wide_ready(code)) return rc;
-  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
-    set_last_error("PGZ with erasures on 16-bit symbols is not supported");
-    return CC_ERR_UNSUPPORTED;
-  }
+  if (int rc = wide_hard_supported(code, erasures != nullptr)) return rc;
   if (B == 0) return CC_OK;
   const size_t n = code->tab.n;
   for (size_t i = 0; i < B * n; ++i)
@@ -993,12 +1183,16 @@ int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in, const uin
   if (sl.rc != CC_OK) return sl.rc;
   HostStage &st = *sl.st;
   const size_t CH = chunk_frames(n * 2, B);
+  if (B > 2 * CH)
+    if (int rc_fs = st.fresh_streams()) return rc_fs;
+  const bool dma_in = HostStage::dma_ready(in), dma_out = HostStage::dma_ready(out),
+             dma_ne = nerr && HostStage::dma_ready(nerr), dma_st = status && HostStage::dma_ready(status);
   size_t k = 0;
   for (size_t c0 = 0; c0 < B; c0 += CH, ++k) {
     const int slot = static_cast<int>(k & 1);
     const size_t m = B - c0 < CH ? B - c0 : CH;
     hipStream_t s = st.stream[slot];
-    CC_HIP_TRY(hipStreamSynchronize(s));
+    if (int r = st.retire(slot)) return r;
     uint16_t *d_in = nullptr, *d_out = nullptr;
     int32_t *d_nerr = nullptr, *d_status = nullptr;
     const uint16_t *d_er = nullptr;
@@ -1007,12 +1201,14 @@ int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in, const uin
     if (int r = st.get(slot, 1, m * n, &d_out)) return r;
     if (int r = st.get(slot, 2, m, &d_nerr)) return r;
     if (int r = st.get(slot, 3, m, &d_status)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(d_in, in + c0 * n, m * n * 2, hipMemcpyHostToDevice, s));
+    if (int r = st.upload(slot, 0, d_in, in + c0 * n, m * n * 2, dma_in)) return r;
     if (int r = upload_erasures(st, slot, 5, erasures, erasure_offsets, c0, m, &d_er, &d_off)) return r;
     if (int r = launch_wide_correct(code, d_in, d_er, d_off, d_out, d_nerr, d_status, m, s)) return r;
-    CC_HIP_TRY(hipMemcpyAsync(out + c0 * n, d_out, m * n * 2, hipMemcpyDeviceToHost, s));
-    if (nerr) CC_HIP_TRY(hipMemcpyAsync(nerr + c0, d_nerr, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (status) CC_HIP_TRY(hipMemcpyAsync(status + c0, d_status, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (int r = st.download(slot, 1, out + c0 * n, d_out, m * n * 2, dma_out)) return r;
+    if (nerr)
+      if (int r = st.download(slot, 2, nerr + c0, d_nerr, m * sizeof(int32_t), dma_ne)) return r;
+    if (status)
+      if (int r = st.download(slot, 3, status + c0, d_status, m * sizeof(int32_t), dma_st)) return r;
   }
   return st.drain();
 }

@@ -107,7 +107,6 @@ struct cc_code {
   uint16_t *d_diag = nullptr;    // [D][LPF] diagonals (row-0 support) dealt to LPF lanes x D slots (minsum_diag)
   uint32_t *d_colbits = nullptr;  // [256] per column: bit i = H[i][col]
   uint8_t *d_parity = nullptr;  // k x l table of x^(k+j) mod g (division_tag encoder)
-  uint64_t *d_emask = nullptr;  // [k*C] wave64 lane masks of the (row, owned column) slots (W == 64 only)
   ccamd::AlgebraicTables *d_alg = nullptr;
   ccamd::AlgebraicTables h_alg;
   mutable ccamd::McWorkspace *mc = nullptr;  // lazily allocated Monte-Carlo chunk buffers
@@ -140,12 +139,6 @@ int hip_fail(hipError_t e, const char *what);
 // minsum.hip
 int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er, const uint32_t *d_er_off,
                   uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream);
-// minsum_reg.hip
-bool minsum_reg_supported(const cc_code *code);
-const char *minsum_reg_name(const cc_code *code);
-int launch_minsum_reg(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
-                      const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
-                      size_t B, hipStream_t stream);
 // minsum_diag.hip
 struct DiagGeometry {
   unsigned n, k, w;  // code length, rows of H, row weight

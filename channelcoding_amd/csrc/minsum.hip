@@ -268,13 +268,6 @@ int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_
     lds = static_cast<uint32_t>(minsum_diag_lds_bytes(*dg));
     return CC_OK;
   }
-  if (minsum_reg_supported(code) && !code->force_generic) {
-    name = minsum_reg_name(code);
-    frames_per_wg = 4;
-    threads = 256;
-    lds = 0;
-    return CC_OK;
-  }
   name = "minsum_generic_kernel<C=" + std::to_string(code->geo.C) + ",W=" + std::to_string(code->geo.W) + ">";
   frames_per_wg = static_cast<uint32_t>(code->geo.frames_per_wave);
   threads = 64;
@@ -303,8 +296,6 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
 
   if (minsum_diag_supported(code) && !code->force_generic)
     return launch_minsum_diag(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
-  if (minsum_reg_supported(code) && !code->force_generic)
-    return launch_minsum_reg(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 
   size_t lds = generic_lds_bytes(code);
   const bool gstate = lds > 160 * 1024;

@@ -126,6 +126,16 @@ static std::vector<uint16_t> build_paired_table(const CodeTables &t, int D, int 
 }
 
 std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np, const int *gap) {
+#ifdef CC_AMD_EXPERIMENTS
+  // timing experiment (results are WRONG): a bank-conflict-free pseudo deal, lane + 16 slot (links: tail, tail + 1)
+  if (const char *e = std::getenv("CC_AMD_EXP_FAKE_DEAL"); e && e[0] == '1') {
+    std::vector<uint16_t> out(static_cast<size_t>(D) * W);
+    for (int d = 0; d < D; ++d)
+      for (int l = 0; l < W; ++l)
+        out[d * W + l] = static_cast<uint16_t>(d < 2 * np ? l + W * (d & ~1) + (d & 1) : l + W * d);
+    return out;
+  }
+#endif
   if (np > 0) return build_paired_table(t, D, W, np, gap);
   std::vector<std::vector<unsigned>> cls(W);
   for (unsigned s : t.row0_support) cls[s % W].push_back(s);
@@ -195,11 +205,7 @@ std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np
 }
 
 bool minsum_diag_supported(const cc_code *code) {
-  static const bool disabled = [] {
-    const char *e = std::getenv("CC_AMD_NO_DIAG");
-    return e && e[0] == '1';
-  }();
-  if (disabled || code->d_diag == nullptr || code->desc.iterations == 0) return false;
+  if (code->d_diag == nullptr || code->desc.iterations == 0) return false;
   const int alg = code->desc.algorithm;
   const DiagGeometry *geo = diag_geometry(code->tab);
   if (!geo) return false;
@@ -303,11 +309,7 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   q.list = list;
   q.list_cap = static_cast<unsigned>(cap);
   // two passes iff fewer than 1 in `den` frames of the sample did not stop (the device tests ctl[2] * 8 < q.sample)
-  static const unsigned den = [] {
-    const char *v = std::getenv("CC_AMD_TWO_PASS_DEN");
-    const int d = v ? std::atoi(v) : 0;
-    return d >= 1 ? static_cast<unsigned>(d) : 8u;
-  }();
+  constexpr unsigned den = 8;  // threshold sweep: profiles/r02_experiments.md, E13
   q.sample = static_cast<unsigned>(sample * 8 / den);
   if (rc == CC_OK) {  // sample
     q.first_pass = 2;

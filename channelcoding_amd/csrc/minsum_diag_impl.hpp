@@ -2,11 +2,11 @@
 // per wavefront, every (lane, slot, row) triple is a real edge of H.  The text below describes the BCH(255,231)
 // instantiation; the template parameters generalise it (see minsum_diag.hip).
 //
-// Why (measured on MI355X, profiles/r01_ubench_instruction_rates.txt): only f32 add/sub/mul issue at
-// ~2.5 cycles per wave instruction; every other VALU op (min/max/med3, integer, compare, select, DPP)
-// costs ~4.3.  The column-parallel register kernel (minsum_reg.hip) spends 96 slot-instructions per
-// frame-iteration at 44 % lane utilisation (H is a band of density 112/255) plus 2 x 6 DPP stages per
-// row for ONE frame.  Here:
+// Why (measured on MI355X, profiles/r01_ubench_instruction_rates.txt, r03_experiments.md): at the two waves per SIMD
+// that 168 message registers allow, a wave issues one instruction per ~7 cycles whatever its class, so what counts is
+// the NUMBER of instructions per frame-iteration.  A column-parallel layout (lane = column, round 1) spends 96
+// slot-instructions per frame-iteration at 44 % lane utilisation (H is a band of density 112/255) plus 2 x 6 DPP
+// stages per row for ONE frame.  Here:
 //   * H is banded Toeplitz (cyclic.h:346-359): edge (row i, diagonal s) sits in column s + i.  The
 //     w = 112 diagonals of BCH(255,231) are dealt 7 to each of 16 lanes, so a frame costs 7 x 24 dense
 //     slot-instructions shared by the 4 frames of the wave (42 per frame-iteration), no EXEC masks,
@@ -23,8 +23,13 @@
 //     LDS by then: global_load_lds copied them there (no VGPR on the way, so nothing the register allocator
 //     could hand to a live value while a load is in flight) during the whole lifetime of the current frame.
 //
-// Numerics are those of minsum_reg.hip (same exclusive-minimum / sign identities, same argument for
-// zeros); configurations outside that argument use the generic kernel.
+// Exactness argument for dropping the explicit zero count of horizontal__ (soft_decision.h:109-118): a zero message
+// only matters through sign = 0 for the OTHER edges of its row, and for those the exclusive minimum is 0, so
+// r = +-h(0) = +-0 for MS / NMS / 2D-NMS / OMS with beta >= 0 -- numerically the reference's 0.  q is never -0.0f
+// (cs starts at +0.0f, y is canonicalised on load), so `q < 0` is exactly signum(q) == -1.  The exclusive minimum
+// (|q| == min1 ? min2 : min1) equals the reference's O(w^2) search, ties included.  Configurations outside that
+// argument (negative offset, non-finite alpha) are routed to the generic kernel by the launcher; SCMS1 / SCMS2 create
+// zeros on purpose and carry their own bookkeeping (BITS1 / KEEPQ below).
 // (kernel template and per-geometry launcher; instantiated by minsum_diag.hip and minsum_diag_small.hip)
 #pragma once
 #include <cstdio>
@@ -150,6 +155,26 @@ __device__ __forceinline__ float max_abs2(float a, float b) {
 __device__ __forceinline__ float min_abs1(float a, float q) {
   float r;
   asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(q));
+  return r;
+}
+__device__ __forceinline__ float med3_abs3(float a, float b, float c) {
+  float r;
+  asm("v_med3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min3_abs3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float med3_abs23(float a, float b, float c) {
+  float r;
+  asm("v_med3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min3_abs23(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 __device__ __forceinline__ float med3_abs1(float a1, float q, float a2) {
@@ -402,7 +427,11 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         // (SINGLE uses y only, but reads the {cs, y} pair all the same: a 4-byte read of the 8-byte cells puts the
         //  two frames of a half-wave on the same 16 of 32 banks -- SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles --
         //  while the 8-byte read spreads them over 64)
+#ifdef CC_EXP_NO_CYR
+        asm volatile("" : "=v"(cyq[d].x), "=v"(cyq[d].y));
+#else
         cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d)));
+#endif
       });
     };
     if constexpr (PREFETCH) fetch(std::integral_constant<int, 0>{});
@@ -427,6 +456,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         float a1 = 0.0f, a2 = (D == 1) ? 3.402823466e+38f : 0.0f;
         uint32_t s = 0;
         uint32_t qs[D];
+        float mag[D];
         // SCMS1: all t = e + y of the row first, their sign / zero bits shifted into two words, ONE three-input bit
         // operation for the keep decision of the whole row, then an arithmetic bit-field extract + AND per edge
         uint32_t keep = 0;
@@ -472,24 +502,28 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             qb &= sgn_keep;
           }
           qs[d] = qb;
-          if constexpr ((SINGLE || BITS1) && !PARTIAL && D >= 2) {  // q is a loaded / masked value here: see min_abs2
-            if constexpr (d == 0) {
-              a1 = q;  // |.| taken by the first use
-            } else if constexpr (d == 1) {
-              a2 = max_abs2(a1, q);
-              a1 = min_abs2(a1, q);
-            } else {
-              a2 = med3_abs1(a1, q, a2);
-              a1 = min_abs1(a1, q);
-            }
-          } else if constexpr (d == 0) {
+          // The lane's two smallest magnitudes.  Values enter three at a time, then two at a time: min3 / med3 give the
+          // two smallest of three; two more values x, y against the sorted pair (a1 <= a2): a1' = min3(a1, x, y) and
+          // a2' = min(a2, med3(a1, x, y)) -- the smallest of the four is the smallest of (a1, x, y), the runner-up the
+          // smaller of that triple's median and a2.  8 instructions for 7 values (one value at a time: 12).
+          // (|.| is a source modifier on all of them; a loaded / masked q goes through the asm forms, see min_abs2.)
+          constexpr bool RAW = (SINGLE || BITS1) && !PARTIAL && D >= 2;
+          mag[d] = RAW ? q : a;
+          if constexpr (D == 2 && d == 1) {
+            a2 = RAW ? max_abs2(mag[0], mag[1]) : __builtin_fmaxf(mag[0], mag[1]);
+            a1 = RAW ? min_abs2(mag[0], mag[1]) : __builtin_fminf(mag[0], mag[1]);
+          } else if constexpr (d == 0 && D == 1) {
             a1 = a;
-          } else if constexpr (d == 1) {
-            a2 = __builtin_fmaxf(a1, a);
-            a1 = __builtin_fminf(a1, a);
-          } else {
-            a2 = __builtin_amdgcn_fmed3f(a1, a, a2);
-            a1 = __builtin_fminf(a1, a);
+          } else if constexpr (d == 2) {
+            a2 = RAW ? med3_abs3(mag[0], mag[1], mag[2]) : __builtin_amdgcn_fmed3f(mag[0], mag[1], mag[2]);
+            a1 = RAW ? min3_abs3(mag[0], mag[1], mag[2]) : __builtin_fminf(__builtin_fminf(mag[0], mag[1]), mag[2]);
+          } else if constexpr (d >= 4 && (d & 1) == 0) {
+            const float md = RAW ? med3_abs23(a1, mag[d - 1], mag[d]) : __builtin_amdgcn_fmed3f(a1, mag[d - 1], mag[d]);
+            a1 = RAW ? min3_abs23(a1, mag[d - 1], mag[d]) : __builtin_fminf(__builtin_fminf(a1, mag[d - 1]), mag[d]);
+            a2 = __builtin_fminf(a2, md);
+          } else if constexpr (d == D - 1 && d >= 3 && (d & 1) == 1) {  // one value left over
+            a2 = RAW ? med3_abs1(a1, mag[d], a2) : __builtin_amdgcn_fmed3f(a1, mag[d], a2);
+            a1 = RAW ? min_abs1(a1, mag[d]) : __builtin_fminf(a1, mag[d]);
           }
         });
         // sign parity: three-input XORs (v_bitop3_b32), half the instructions of a chain of v_xor_b32
@@ -513,9 +547,15 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         else if constexpr (SINGLE)
           cn[d] = cyq[d].x;
         else
+#ifdef CC_EXP_NO_CNR
+          asm volatile("" : "=v"(cn[d]));
+#else
           cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
+#endif
       });
+#ifndef CC_EXP_NO_REDUCE
       row_allreduce<1, LPF>(m1, m2, sg);
+#endif
       // the parity leaves the last DPP stage in a register of its own: folded into the mask below, the compiler
       // undoes the DPP form of that stage (a bit operation with three inputs takes no DPP operand)
       asm volatile("" : "+v"(sg[0]));
@@ -526,7 +566,12 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         // XOR with m1 ^ m2 swaps the two magnitudes, XOR with the row parity (bit 31) turns sign(q) into the
         // product of the OTHER signs.  A zero keeps its sign bit through med3, as it did through the old
         // (t ^ Y) + signbit(q) form; with m1 = m2 = 0 the result is +-0 either way.
-        const uint32_t Y = (m1[0] ^ m2[0]) | sign31;
+        uint32_t Y = (m1[0] ^ m2[0]) | sign31;
+#ifndef CC_EXP_BITOP3_POST
+        // Y in a register of its own: otherwise the compiler folds the OR into every edge's XOR (v_bitop3_b32 with three
+        // inputs, a half-rate VOP3 encoding) where a plain v_xor_b32 issues at the full rate
+        asm volatile("" : "+v"(Y));
+#endif
         const float hi = u2f(m2[0]);
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
@@ -556,7 +601,11 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         else if constexpr (SINGLE)
           *reinterpret_cast<float *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
         else
+#ifdef CC_EXP_NO_CNW
+          asm volatile("" ::"v"(sum[d]));
+#else
           *reinterpret_cast<float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
+#endif
       });
       // The next row reads column sums that OTHER lanes have just written (column s + i is diagonal s - 1 of
       // row i + 1).  The hardware keeps LDS operations of a wavefront in order; the compiler must too: per
@@ -603,6 +652,9 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       stop_scan(std::false_type{});
       ok = (p.stop_rule == CC_STOP_AS_SHIPPED) || group_xor<LPF>(acc) == 0;
     }
+#ifdef CC_EXP_NEVER_STOP
+    ok = false;
+#endif
     const bool finished = SINGLE || ok || (it + 1 >= p.iterations);
     if (finished && active) {
       const unsigned long long done = frame;

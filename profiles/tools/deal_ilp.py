@@ -1,0 +1,81 @@
+"""Exact search (mixed-integer program, scipy / HiGHS) for a bank-conflict-free deal -- see deal_search.py for the model."""
+import sys
+import numpy as np
+from scipy.optimize import milp, LinearConstraint, Bounds
+from scipy.sparse import lil_matrix
+from deal_model import SUPPORT_255_231
+
+
+def solve(sup, NL, NS, W, delta, mod=32, same=False, wmax=2, time_limit=120):
+    S = set(sup)
+    idx = {s: i for i, s in enumerate(sup)}
+    n = len(sup)
+    roles = ["t%d" % k for k in range(NL)] + ["h%d" % k for k in range(NL)] + ["s%d" % k for k in range(NS)]
+    R = len(roles)
+    P = 1 if same else 2
+    nv = P * n * R
+    var = lambda p, s, r: (p * n + idx[s]) * R + r
+    rows = []
+    lo = []
+    hi = []
+    def add(coefs, l, h):
+        rows.append(coefs); lo.append(l); hi.append(h)
+    for p in range(P):
+        for s in sup:
+            add([(var(p, s, r), 1) for r in range(R)], 1, 1)  # one role
+            for k in range(NL):
+                # tail k at s <=> head k at s+1
+                if s + 1 in S:
+                    add([(var(p, s, k), 1), (var(p, s + 1, NL + k), -1)], 0, 0)
+                else:
+                    add([(var(p, s, k), 1)], 0, 0)
+                if s - 1 not in S:
+                    add([(var(p, s, NL + k), 1)], 0, 0)
+        for r in range(R):
+            add([(var(p, s, r), 1) for s in sup], W, W)
+    # banks
+    for r in range(R):
+        is_read = r >= NL
+        is_write = r < NL or r >= 2 * NL
+        for b in range(mod):
+            coefs = [(var(0, s, r), 1) for s in sup if s % mod == b]
+            if same:
+                coefs += [(var(0, s, r), 1) for s in sup if (s + delta) % mod == b]
+            else:
+                coefs += [(var(1, s, r), 1) for s in sup if (s + delta) % mod == b]
+            if not coefs:
+                continue
+            if is_read:
+                add(coefs, 1, 1)
+            elif is_write:
+                add(coefs, 0, wmax)
+    A = lil_matrix((len(rows), nv))
+    for i, c in enumerate(rows):
+        for j, v in c:
+            A[i, j] += v
+    res = milp(c=np.zeros(nv), constraints=LinearConstraint(A.tocsr(), lo, hi), integrality=np.ones(nv),
+               bounds=Bounds(0, 1), options={"time_limit": time_limit, "disp": False})
+    if res.x is None:
+        return None
+    x = np.round(res.x).astype(int)
+    out = []
+    for p in range(P):
+        deal = {r: [] for r in roles}
+        for s in sup:
+            for r in range(R):
+                if x[var(p, s, r)]:
+                    deal[roles[r]].append(s)
+        out.append(deal)
+    return out
+
+
+if __name__ == "__main__":
+    import scipy
+    print("scipy", scipy.__version__)
+    for delta in [int(a) for a in sys.argv[1].split(",")]:
+        r = solve(SUPPORT_255_231, 2, 3, 16, delta, time_limit=int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+        print("delta", delta, "feasible" if r else "none/timeout")
+        if r:
+            for p, d in enumerate(r):
+                print(" parity", p, d)
+            break

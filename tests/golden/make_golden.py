@@ -153,14 +153,55 @@ def mult_golden(ref0):
     np.savez_compressed(os.path.join(HERE, "mult.npz"), **d)
 
 
+def headline_golden(ref0, ref1):
+    """SURVEY 8(c) F-MS for the headline code: BCH(255,231) MS<20> family, 256 frames at each of 2 / 4 / 6 dB (half
+    all-zero words, half random codewords), every variant setting x O0 / O1 / O2 = 27 cases from the real reference
+    (a few minutes on 8 cores: ctypes releases the GIL).  Hard decisions, iteration index and failure flag for every
+    frame; L for the first LSUB frames of each Eb/N0 block (the full L would be 21 MB)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cid, iters, per, LSUB = 6, 20, 256, 16
+    fam, q, t = REF_CODES[cid]
+    o = Oracle(fam, q, t)
+    rng = np.random.default_rng(2600)
+    ys, sent = [], []
+    for e in (2.0, 4.0, 6.0):
+        c = np.concatenate([np.zeros((per // 2, o.n), np.uint8),
+                            ref0.encode(cid, rng.integers(0, 2, (per // 2, o.l)).astype(np.uint8))])
+        sent.append(c)
+        ys.append(awgn_llr(rng, c, o.l / o.n, e))
+    y = np.concatenate(ys)
+    lsel = np.concatenate([np.arange(k * per, k * per + LSUB) for k in range(3)])
+    d = dict(y=y, sent=np.packbits(np.concatenate(sent), axis=1), iterations=np.array(iters), lsel=lsel)
+    cases = [(v, rule, lib, utype) for v in sorted(REF_VARIANTS)
+             for rule, (lib, utype) in (("o0", (ref0, 0)), ("o1", (ref1, 0)), ("o2", (ref1, 1)))]
+
+    def run(case):
+        v, rule, lib, utype = case
+        parts = [lib.minsum(cid, v, iters, utype, y[i:i + 32]) for i in range(0, len(y), 32)]
+        return case, [np.concatenate([p[k] for p in parts]) for k in range(4)]
+
+    with ThreadPoolExecutor(8) as ex:
+        for (v, rule, _, _), (b, L, it, st) in ex.map(run, cases):
+            key = "v%d_%s" % (v, rule)
+            d[key + "_b"] = np.packbits(b, axis=1)
+            d[key + "_L"] = L[lsel]
+            d[key + "_it"] = it.astype(np.uint16)
+            d[key + "_st"] = st.astype(np.int8)
+            print(key, "failures", int((st != 0).sum()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "minsum_bch255_231_headline.npz"), **d)
+
+
 def main():
     ref0, ref1 = RefLib.get(0), RefLib.get(1)
+    if sys.argv[1:] == ["headline"]:
+        return headline_golden(ref0, ref1)
     if sys.argv[1:] == ["alt"]:
         return alt_golden(ref0, ref1)
     if sys.argv[1:] == ["mult"]:
         return mult_golden(ref0)
     alt_golden(ref0, ref1)
     mult_golden(ref0)
+    headline_golden(ref0, ref1)
     with open(os.path.join(HERE, "constants.json"), "w") as f:
         json.dump(constants(ref0), f, indent=1)
     with open(os.path.join(HERE, "exercises.json"), "w") as f:

@@ -42,6 +42,25 @@ def minsum_cases(cid):
                 np.int32)
 
 
+def minsum_headline_cases():
+    """BCH(255,231) MS<20> family, 256 frames at each of 2 / 4 / 6 dB (minsum_bch255_231_headline.npz): y, iterations,
+    the frame indices whose L is stored, and an iterator of (variant_id, (oracle_variant, alpha, beta), rule_id, b, L
+    [of those frames], it, st)."""
+    d = np.load(os.path.join(GOLDEN, "minsum_bch255_231_headline.npz"), allow_pickle=False)
+    y = d["y"]
+    width = y.shape[1]
+
+    def cases():
+        for v in sorted(REF_VARIANTS):
+            for rule, rid in RULES.items():
+                key = "v%d_%s" % (v, rule)
+                b = np.unpackbits(d[key + "_b"], axis=1)[:, :width]
+                yield v, REF_VARIANTS[v], rid, b, d[key + "_L"], d[key + "_it"].astype(np.uint32), d[key + "_st"].astype(
+                    np.int32)
+
+    return y, int(d["iterations"]), d["lsel"], cases()
+
+
 ALT_CIDS = (0, 1, 5, 6)
 
 

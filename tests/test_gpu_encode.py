@@ -52,7 +52,7 @@ def test_encode_errors():
     assert code.encode_batch(np.zeros((0, 9), np.uint8)).shape == (0, 15)
 
 
-@pytest.mark.parametrize("cid,log2b", [(6, 20), (10, 18)])
+@pytest.mark.parametrize("cid,log2b", [(6, 20), (10, 18), (10, 20)])  # (10, 20) = BASELINE configs[3] at full size
 def test_full_size_roundtrip(cid, log2b):
     """BASELINE sizes through size-independent properties, all on device:
     every codeword has zero syndromes (decoder returns it untouched with nerr = 0);
@@ -85,6 +85,41 @@ def test_full_size_roundtrip(cid, log2b):
     assert int((res["status"] != 0).sum()) == 0
     assert torch.equal(res["out"], cw)
     assert torch.equal(res["nerr"], nerr.to(torch.int32))
+
+
+def test_rs255_223_full_size_against_the_oracle():
+    """BASELINE configs[3] at its full size: RS(255,223), 2^20 frames, 0..18 random symbol errors per frame (two
+    beyond the capability), Berlekamp-Massey: the seven-kernel bit-plane path on the whole batch; 2048 frames sampled
+    at a stride are compared with the oracle frame for frame (corrected word, error count, failure class), every frame
+    within the capability must come back as the transmitted word."""
+    import torch
+    from checkers import BM
+    from test_gpu_algebraic import check_against_oracle
+    code = make_code(10)
+    o = Oracle(RS, 8, 16)
+    B, t = 1 << 20, 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1020)
+    msg = torch.randint(0, 256, (B, code.l), dtype=torch.uint8, device="cuda", generator=g)
+    cw = code.encode_batch(msg)
+    nerr = torch.randint(0, t + 3, (B,), device="cuda", generator=g)
+    perm = torch.rand((B, code.n), device="cuda", generator=g).argsort(dim=1)[:, :t + 2]
+    vals = torch.randint(1, 256, (B, t + 2), dtype=torch.uint8, device="cuda", generator=g)
+    vals = torch.where(torch.arange(t + 2, device="cuda")[None, :] < nerr[:, None], vals, torch.zeros_like(vals))
+    del msg
+    rx = cw.clone()
+    rx.scatter_(1, perm, rx.gather(1, perm) ^ vals)
+    del perm, vals
+    res = code.correct_batch(rx)
+    easy = nerr <= t
+    assert int((res["status"][easy] != 0).sum()) == 0
+    assert torch.equal(res["out"][easy], cw[easy]) and torch.equal(res["nerr"][easy], nerr[easy].to(torch.int32))
+    hard = ~easy  # beyond the capability: a failure, or a mis-correction to another codeword (then H c = 0 again)
+    bad = res["status"][hard] != 0
+    assert torch.equal(res["out"][hard][bad], rx[hard][bad])
+    idx = torch.arange(0, B, B // 2048, device="cuda")
+    sample = {k: v[idx].cpu().numpy() for k, v in res.items()}
+    check_against_oracle(sample, o, BM, rx[idx].cpu().numpy())
 
 
 @pytest.mark.parametrize("cid", G.MULT_CIDS)

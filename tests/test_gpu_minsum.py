@@ -65,6 +65,26 @@ def test_minsum_golden(cid):
         check(res, ob, oL, oit, ost, (v, rule))
 
 
+def test_minsum_headline_golden():
+    """HIP path vs the real reference on the headline code (SURVEY 8c F-MS): 768 frames at 2 / 4 / 6 dB, all-zero and
+    random codewords, 9 variant settings x O0 / O1 / O2 (tests/golden/minsum_bch255_231_headline.npz) -- at 4 dB most of
+    the frames run all 20 iterations and fail, the regime the bench is quoted on.  Failed frames carry no reference
+    output (it throws): those are compared with the oracle."""
+    y, iters, lsel, cases = G.minsum_headline_cases()
+    o = Oracle(*REF_CODES[6])
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in cases:
+        code = make_code(6, ov, alpha, beta, iters, rule)
+        res = code.correct_batch(y, want_L=True)
+        ok = gst == 0
+        assert np.array_equal(res["status"] != 0, gst != 0), (v, rule)
+        assert np.array_equal(res["out"][ok], gb[ok]), (v, rule)
+        assert np.array_equal(res["iters"][ok], git[ok]), (v, rule)
+        okl = ok[lsel]
+        assert np.allclose(res["L"][lsel][okl], gL[okl], rtol=0, atol=1e-5), (v, rule)
+        ob, oL, oit, ost = o.minsum(ov, iters, y, alpha, beta, rule, fast=True)
+        check(res, ob, oL, oit, ost, (v, rule))
+
+
 @pytest.mark.parametrize("cid,iters,frames", [(0, 10, 301), (1, 10, 130), (4, 50, 203), (12, 20, 97), (5, 10, 257),
                                               (13, 10, 66), (11, 20, 65), (6, 20, 48)])
 def test_minsum_vs_oracle_seeded(cid, iters, frames):
@@ -296,12 +316,11 @@ def test_minsum_extreme_code_parameters(q, t):
         check(code.correct_batch(y, want_L=True), *o.minsum(ov, 10, y, alpha, beta, rule, fast=True), tag=(q, t, ov))
 
 
-@pytest.mark.parametrize("env,expect", [({"CC_AMD_NO_DIAG": "1"}, "minsum_reg_kernel"),
-                                        ({"CC_AMD_FORCE_GENERIC": "1"}, "minsum_generic_kernel")])
+@pytest.mark.parametrize("env,expect", [({"CC_AMD_FORCE_GENERIC": "1"}, "minsum_generic_kernel")])
 def test_fallback_kernels_stay_exact(env, expect):
-    """The diagonal kernel now covers every code the register-resident kernel was written for, and both shadow
-    the generic kernel: run the seeded oracle comparison again in a child process with the dispatch overrides
-    (read once per process) so the two fallbacks keep their parity coverage."""
+    """The diagonal kernel shadows the generic kernel on every code with a geometry: run the seeded oracle
+    comparison again in a child process with the dispatch override (read once per process) so the fallback keeps
+    its parity coverage."""
     import os
     import subprocess
     import sys

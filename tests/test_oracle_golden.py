@@ -102,6 +102,21 @@ def test_minsum_golden(cid):
         assert np.array_equal(b[ok], gb[sub][ok]) and np.array_equal(L[ok], gL[sub][ok])
 
 
+def test_minsum_headline_golden():
+    """SURVEY 8(c) F-MS for the headline code: 768 frames (2 / 4 / 6 dB, all-zero and random codewords) x 9 variant
+    settings x O0 / O1 / O2 from the real reference -- at 4 dB most frames run all 20 iterations and fail."""
+    o = oracle_for(6)
+    y, iters, lsel, cases = G.minsum_headline_cases()
+    for v, (ov, alpha, beta), rule, gb, gL, git, gst in cases:
+        b, L, it, st = o.minsum(ov, iters, y, alpha, beta, rule, fast=True)
+        assert np.array_equal(st != 0, gst != 0), (v, rule)
+        ok = st == 0
+        assert np.array_equal(b[ok], gb[ok]), (v, rule)
+        assert np.array_equal(it[ok], git[ok]), (v, rule)
+        okl = ok[lsel]
+        assert np.allclose(L[lsel][okl], gL[okl], rtol=0, atol=1e-5), (v, rule)
+
+
 @pytest.mark.parametrize("cid", G.ALT_CIDS)
 def test_minsum_alt_golden(cid):
     """H_alt and min-sum over it against the reference's committed outputs."""
