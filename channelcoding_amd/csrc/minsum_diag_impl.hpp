@@ -140,6 +140,65 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return LPF == 16 ? or_stage<0x140>(v) : v;
 }
 
+// Reduction of FOUR rows at once inside a 16-lane DPP row (see the TRED branch of the kernel).  In: per lane the sorted
+// pair (a1 <= a2, bit patterns of non-negative floats) and the sign word of rows 0..3.  Out: in the four lanes of bank b
+// (lanes 4b..4b+3) the row's minimum, second minimum with multiplicity and sign parity (bit 31) of ROW b.
+// One asm statement: the assembler inserts no wait states inside inline asm, so the order below keeps every register
+// at least two instructions between its VALU write and a DPP read of it (the inputs of rows 0 and 2 are the oldest:
+// they go first).  A DPP instruction with a bank mask leaves its destination untouched in the other banks, so each
+// kept value is written by two instructions, one per half of the banks.
+__device__ __forceinline__ void transposed_reduce4(const uint32_t (&a1)[4], const uint32_t (&a2)[4], const uint32_t (&sg)[4],
+                                                   uint32_t &z1, uint32_t &z2, uint32_t &zs) {
+  uint32_t x1, x2, xs, y1, y2, ys, h, t, h2, t2;
+  asm volatile(
+      // (a register copy the compiler may have placed right in front of this statement must have landed)
+      "s_nop 1\n\t"
+      // stage 1, lane bit 3 (partner = lane ^ 8 = row_ror:8): banks 0,1 keep rows 0 / 1, banks 2,3 keep rows 2 / 3
+      "v_max_u32_dpp %[h], %[a10], %[a10] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_max_u32_dpp %[h], %[a12], %[a12] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32_dpp %[x1], %[a10], %[a10] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_min_u32_dpp %[x1], %[a12], %[a12] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32_dpp %[t], %[a20], %[a20] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_min_u32_dpp %[t], %[a22], %[a22] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_xor_b32_dpp %[xs], %[s0], %[s0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_xor_b32_dpp %[xs], %[s2], %[s2] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32 %[x2], %[t], %[h]\n\t"
+      "v_max_u32_dpp %[h2], %[a11], %[a11] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_max_u32_dpp %[h2], %[a13], %[a13] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32_dpp %[y1], %[a11], %[a11] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_min_u32_dpp %[y1], %[a13], %[a13] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32_dpp %[t2], %[a21], %[a21] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_min_u32_dpp %[t2], %[a23], %[a23] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_xor_b32_dpp %[ys], %[s1], %[s1] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_xor_b32_dpp %[ys], %[s3], %[s3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_min_u32 %[y2], %[t2], %[h2]\n\t"
+      // stage 2, lane bit 2 (partner = lane ^ 4): banks 0,2 keep x (read lane + 4), banks 1,3 keep y (read lane - 4)
+      "v_max_u32_dpp %[h], %[x1], %[x1] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_min_u32_dpp %[z1], %[x1], %[x1] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_min_u32_dpp %[t], %[x2], %[x2] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_xor_b32_dpp %[zs], %[xs], %[xs] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_max_u32_dpp %[h], %[y1], %[y1] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_min_u32_dpp %[z1], %[y1], %[y1] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_min_u32_dpp %[t], %[y2], %[y2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_xor_b32_dpp %[zs], %[ys], %[ys] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_min_u32 %[z2], %[t], %[h]\n\t"
+      // stages 3 and 4, inside the quads (butterfly: every lane of a bank ends with the bank's row)
+      "v_max_u32_dpp %[h], %[z1], %[z1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_u32_dpp %[z1], %[z1], %[z1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_xor_b32_dpp %[zs], %[zs], %[zs] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[t], %[z2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min3_u32 %[z2], %[h], %[z2], %[t]\n\t"
+      "v_max_u32_dpp %[h], %[z1], %[z1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_u32_dpp %[z1], %[z1], %[z1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_xor_b32_dpp %[zs], %[zs], %[zs] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[t], %[z2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min3_u32 %[z2], %[h], %[z2], %[t]"
+      : [x1] "=&v"(x1), [x2] "=&v"(x2), [xs] "=&v"(xs), [y1] "=&v"(y1), [y2] "=&v"(y2), [ys] "=&v"(ys), [h] "=&v"(h),
+        [t] "=&v"(t), [h2] "=&v"(h2), [t2] "=&v"(t2), [z1] "=&v"(z1), [z2] "=&v"(z2), [zs] "=&v"(zs)
+      : [a10] "v"(a1[0]), [a11] "v"(a1[1]), [a12] "v"(a1[2]), [a13] "v"(a1[3]), [a20] "v"(a2[0]), [a21] "v"(a2[1]),
+        [a22] "v"(a2[2]), [a23] "v"(a2[3]), [s0] "v"(sg[0]), [s1] "v"(sg[1]), [s2] "v"(sg[2]), [s3] "v"(sg[3]));
+}
+
 // |.|-modified minimum / maximum / median without the canonicalisation the compiler puts in front of fminf on a
 // value that comes straight from memory (the hardware instructions quiet a signalling NaN themselves)
 __device__ __forceinline__ float min_abs2(float a, float b) {
@@ -413,6 +472,15 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     //  the bit words below take the 14 registers the prefetch would hold)
     // (SINGLE: the cs' half of a cell is written by the row before, so a row's operands are fetched when it starts)
     constexpr bool PREFETCH = !(BITS1 && K * D >= 160) && !SINGLE;
+    // four rows per (transposed) reduction, see below: bit-exact and 180 instructions per iteration shorter, but
+    // measured 1.4 % SLOWER than the butterfly (profiles/r03_experiments.md, E19: the reduction was what covered the LDS
+    // latency of each row's operands; without it the schedule needs four counted waits per row) -- experiments only
+#ifdef CC_EXP_TRED
+    constexpr bool TRED = LPF == 16 && K % 4 == 0 && !SINGLE;
+#else
+    constexpr bool TRED = false;
+#endif
+    constexpr bool EARLY_PF = TRED && PREFETCH;
     float2 cyq[D];
     float2 carry_cy[NLK ? NLK : 1];  // the head's operands of the row before: the tail's operands of this row
     float carry_sum[NLK ? NLK : 1];  // the head's running column sum of the row before
@@ -434,13 +502,14 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 #endif
       });
     };
-    if constexpr (PREFETCH) fetch(std::integral_constant<int, 0>{});
-    static_for<K>([&](auto IR) {
-      constexpr int i = IR;
+    float Tloc[D];  // SINGLE: q, then r, of the row in hand (nothing is kept across rows)
+    // ---- a row in three parts, so that the reduction between them can serve one row (butterfly) or four (transposed) ----
+    // front: operands, q = (cs - r) + y, the lane's two smallest magnitudes and its sign parity
+    auto row_front = [&](auto IR, uint32_t &o1, uint32_t &o2, uint32_t &os) {
+      constexpr int i = decltype(IR)::value;
       if constexpr (!PREFETCH) fetch(IR);
       // q, then r, of this row's edges: the message registers, or temporaries when nothing is kept
       // (accessors with literal indices: a reference to R[i] would keep the whole array out of registers)
-      float Tloc[D];
       auto wget = [&](auto DD) -> float {
         if constexpr (SINGLE) return Tloc[DD];
         else return R[i][DD];
@@ -449,14 +518,13 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         if constexpr (SINGLE) Tloc[DD] = v;
         else R[i][DD] = v;
       };
-      uint32_t m1[1], m2[1], sg[1];
       {
         // with one diagonal per lane the lane's second minimum is "none": numeric_limits<float>::max(), the
         // starting value of the reference's own search (soft_decision.h:110); with D >= 2 both are overwritten
         float a1 = 0.0f, a2 = (D == 1) ? 3.402823466e+38f : 0.0f;
         uint32_t s = 0;
         uint32_t qs[D];
-        float mag[D];
+        float mag[D], qv[D];
         // SCMS1: all t = e + y of the row first, their sign / zero bits shifted into two words, ONE three-input bit
         // operation for the keep decision of the whole row, then an arithmetic bit-field extract + AND per edge
         uint32_t keep = 0;
@@ -495,6 +563,22 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             }
           }
           wset(DD, q);
+          qv[d] = q;
+        });
+        // TRED: nothing hides the operands' latency between two fronts (the reduction comes after the fourth), so the
+        // next row's operands are requested as soon as this row's have been consumed -- the pair tracking and the sign
+        // parity below (~12 instructions) run while they travel
+        if constexpr (EARLY_PF) {
+          static_for<NLK>([&](auto P) { carry_cy[P] = cyq[2 * P + 1]; });
+          // (one row's requests per barrier: merged across rows they become ds_read2_b64, which costs the LDS twice
+          //  the cycles of two ds_read_b64 -- profiles/r02_experiments.md E3 -- and keeps four rows of operands live)
+          asm volatile("" ::: "memory");
+          if constexpr (i + 1 < K) fetch(std::integral_constant<int, i + 1>{});
+          asm volatile("" ::: "memory");
+        }
+        static_for<D>([&](auto DD) {
+          constexpr int d = DD;
+          const float q = qv[d];
           float a = __builtin_fabsf(q);
           uint32_t qb = f2u(q);
           if constexpr (PARTIAL && d == D - 1) {
@@ -533,13 +617,18 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
                                                                 static_cast<int>(qs[2 + 2 * T]), 0x96));  // a ^ b ^ c
         });
         if constexpr ((D - 1) % 2) s ^= qs[D - 1];
-        m1[0] = f2u(a1);
-        m2[0] = f2u(a2);
-        sg[0] = s;
+        o1 = f2u(a1);
+        o2 = f2u(a2);
+        os = s;
       }
-      static_for<NLK>([&](auto P) { carry_cy[P] = cyq[2 * P + 1]; });
-      if constexpr (PREFETCH && i + 1 < K) fetch(std::integral_constant<int, i + 1>{});  // the next row's operands
-      float cn[D];
+      if constexpr (!EARLY_PF) {
+        static_for<NLK>([&](auto P) { carry_cy[P] = cyq[2 * P + 1]; });
+        if constexpr (PREFETCH && i + 1 < K) fetch(std::integral_constant<int, i + 1>{});  // the next row's operands
+      }
+    };
+    // column sums accumulated so far, requested before the reduction so that their latency hides behind it
+    auto row_cn = [&](auto IR, float (&cn)[D]) {
+      constexpr int i = decltype(IR)::value;
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
         if constexpr (d < 2 * NLK && (d & 1) == 0 && i >= 1)
@@ -553,36 +642,45 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           cn[d] = *reinterpret_cast<const float *>(cn_lane + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d)));
 #endif
       });
-#ifndef CC_EXP_NO_REDUCE
-      row_allreduce<1, LPF>(m1, m2, sg);
-#endif
+    };
+    // back: r from the row's minima and parity, then the column sums (soft_decision.h:101-122, :86-98)
+    auto row_back = [&](auto IR, uint32_t m1v, uint32_t m2v, uint32_t sg0, float (&cn)[D]) {
+      constexpr int i = decltype(IR)::value;
+      auto wget = [&](auto DD) -> float {
+        if constexpr (SINGLE) return Tloc[DD];
+        else return R[i][DD];
+      };
+      auto wset = [&](auto DD, float v) {
+        if constexpr (SINGLE) Tloc[DD] = v;
+        else R[i][DD] = v;
+      };
       // the parity leaves the last DPP stage in a register of its own: folded into the mask below, the compiler
       // undoes the DPP form of that stage (a bit operation with three inputs takes no DPP operand)
-      asm volatile("" : "+v"(sg[0]));
-      const uint32_t sign31 = sg[0] & 0x80000000u;
+      asm volatile("" : "+v"(sg0));
+      const uint32_t sign31 = sg0 & 0x80000000u;
       if constexpr (VARIANT == CC_ALG_MS || VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2) {  // h(m) = m
         // exclusive minimum with the exclusive sign in TWO instructions per edge: u = med3(q, -m2, m2) is
         // sign(q) min(|q|, m2), i.e. +-m1 for the holder of the minimum and +-m2 for everybody else (|q| >= m2);
         // XOR with m1 ^ m2 swaps the two magnitudes, XOR with the row parity (bit 31) turns sign(q) into the
         // product of the OTHER signs.  A zero keeps its sign bit through med3, as it did through the old
         // (t ^ Y) + signbit(q) form; with m1 = m2 = 0 the result is +-0 either way.
-        uint32_t Y = (m1[0] ^ m2[0]) | sign31;
+        uint32_t Y = (m1v ^ m2v) | sign31;
 #ifndef CC_EXP_BITOP3_POST
         // Y in a register of its own: otherwise the compiler folds the OR into every edge's XOR (v_bitop3_b32 with three
         // inputs, a half-rate VOP3 encoding) where a plain v_xor_b32 issues at the full rate
         asm volatile("" : "+v"(Y));
 #endif
-        const float hi = u2f(m2[0]);
+        const float hi = u2f(m2v);
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
           wset(DD, u2f(f2u(__builtin_amdgcn_fmed3f(wget(DD), -hi, hi)) ^ Y));
         });
       } else {
-        const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1[0]), p.alpha_f, p.beta_d));
-        const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2[0]), p.alpha_f, p.beta_d));
+        const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1v), p.alpha_f, p.beta_d));
+        const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2v), p.alpha_f, p.beta_d));
         static_for<D>([&](auto DD) {
           constexpr int d = DD;
-          const uint32_t mag = (__builtin_fabsf(wget(DD)) == u2f(m1[0])) ? H2 : H1;
+          const uint32_t mag = (__builtin_fabsf(wget(DD)) == u2f(m1v)) ? H2 : H1;
           wset(DD, u2f(xad(mag, sign31, f2u(wget(DD)) & 0x80000000u)));
         });
       }
@@ -612,32 +710,90 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       // lane the two addresses differ by a constant, so without this barrier it may hoist the next row's read
       // above this row's write (it did for D = 1, where nothing else sits between them).
       asm volatile("" ::: "memory");
-    });
+    };
+    if constexpr (PREFETCH) fetch(std::integral_constant<int, 0>{});
+    if constexpr (TRED) {
+      // Four rows per reduction (LPF = 16, K a multiple of four).  A butterfly all-reduce leaves every lane with every
+      // row's result at (4 + 1) instructions x 4 stages per row; here the first two stages HALVE the data instead:
+      // across lane bit 3 the lanes of banks 0, 1 keep rows 0, 1 of the group and hand rows 2, 3 to their partners
+      // in banks 2, 3 (and the other way round), across lane bit 2 the same again, so that bank b ends up with row b
+      // alone -- DPP bank masks select the writing lanes, so "keep mine, take yours" costs no select instruction
+      // (7 + 2 instructions per row PAIR and stage) -- and only two butterfly stages inside the quads remain, on one
+      // row per lane: 37 instructions per four rows instead of 80.  ds_swizzle hands a bank's result to the other
+      // three (12 per group, LDS crossbar, no memory access).
+      static_for<K / 4>([&](auto IG) {
+        constexpr int g = IG;
+        uint32_t a1[4], a2[4], sg[4];
+        static_for<4>([&](auto J) { row_front(std::integral_constant<int, 4 * g + J>{}, a1[J], a2[J], sg[J]); });
+        uint32_t z1, z2, zs;
+        transposed_reduce4(a1, a2, sg, z1, z2, zs);
+        uint32_t M1[4], M2[4], SG[4];
+        static_for<4>([&](auto J) {
+          constexpr int pat = 0x13 | (J << 7);  // bit mode: lane' = (lane & 0x13) | (J << 2): bank J of the own 16-lane row
+          M1[J] = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(z1), pat));
+          M2[J] = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(z2), pat));
+          SG[J] = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(zs), pat));
+        });
+        static_for<4>([&](auto J) {
+          float cn[D];
+          row_cn(std::integral_constant<int, 4 * g + J>{}, cn);
+          row_back(std::integral_constant<int, 4 * g + J>{}, M1[J], M2[J], SG[J], cn);
+        });
+      });
+    } else {
+      static_for<K>([&](auto IR) {
+        uint32_t m1[1], m2[1], sg[1];
+        row_front(IR, m1[0], m2[0], sg[0]);
+        float cn[D];
+        row_cn(IR, cn);
+#ifndef CC_EXP_NO_REDUCE
+        row_allreduce<1, LPF>(m1, m2, sg);
+#endif
+        row_back(IR, m1[0], m2[0], sg[0], cn);
+      });
+    }
 
     // ---------------- a-posteriori values, stop test (soft_decision.h:178-186) ----------------
     // acc: XOR of the check masks of the columns whose hard decision is 1 (the frame's syndrome, GF(2) rule O2) or
     // their OR (rule O1: only the all-zero word passes).  Only the last owned column can lie beyond the frame.
     uint32_t acc = 0;
+    // All reads first, then the arithmetic, then the writes: written column by column (read, test, write) the compiler
+    // must keep every column's reads behind the previous column's writes -- it cannot tell the addresses apart -- and
+    // the scan pays one LDS round trip per column, 16 per iteration (round 2: 8 % of the kernel's time).  The check
+    // masks come along unconditionally (one v_cndmask per column instead of a read under EXEC = hard decision).
     auto stop_scan = [&](auto ORC) {
+      float cnv[CPL], yc[CPL];
+      uint32_t cb[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        float cnv, yc;
         if constexpr (SINGLE) {
           const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs', y}
-          cnv = cy.x;
-          yc = cy.y;
+          cnv[c] = cy.x;
+          yc[c] = cy.y;
         } else {
-          cnv = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
-          yc = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
+          cnv[c] = *reinterpret_cast<const float *>(cn_lane + (col0 + LPF * c) * 8);
+          yc[c] = *reinterpret_cast<const float *>(cy_base + (col0 + LPF * c) * 8 + 4);
         }
-        bool bit = cnv + yc < 0.0f;  // L = cs + y :180-182, b = L < 0 codes.h:51
-        if (c == CPL - 1) bit = bit && (lam + LPF * c < n);
-        const uint32_t cb = bit ? cbits[lam + LPF * c] : 0u;
-        if constexpr (decltype(ORC)::value) acc |= cb;
-        else acc ^= cb;
-        // next iteration: cs := cs', cs' := 0 (SINGLE: there is none, and cs' already sits in the cell)
-        if constexpr (!SINGLE) {
-          *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv;
+        cb[c] = cbits[lam + LPF * c];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        // L = cs + y :180-182, b = L < 0 codes.h:51.  L is never -0.0f (cs' is a sum that started at +0.0f, y was
+        // canonicalised on load), so b is L's sign bit: spread it over the word (one shift) and fold mask and
+        // accumulation into one three-input bit operation -- no compare, no select, no VCC.  Columns beyond the frame
+        // (only the last owned one can be) have an all-zero check mask.
+        const int m = static_cast<int>(f2u(cnv[c] + yc[c])) >> 31;
+        if constexpr (decltype(ORC)::value)
+          acc = static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int>(acc), m, static_cast<int>(cb[c]), 0xF8));  // a | (b & c)
+        else
+          acc = static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int>(acc), m, static_cast<int>(cb[c]), 0x78));  // a ^ (b & c)
+      }
+      // next iteration: cs := cs', cs' := 0 (SINGLE: there is none, and cs' already sits in the cell)
+      if constexpr (!SINGLE) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          *reinterpret_cast<float *>(cy_base + (col0 + LPF * c) * 8) = cnv[c];
           *reinterpret_cast<float *>(cn_lane + (col0 + LPF * c) * 8) = 0.0f;
         }
       }
