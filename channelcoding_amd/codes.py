@@ -361,7 +361,7 @@ class cyclic:
         """Returns a dict: out (B,n) u8, status (B,) i32, and nerr (hard) or iters [+ L] (soft)."""
         lib = capi.lib()
         soft_alg = self.algorithm.soft
-        if self.wide:
+        if self.wide and not soft_alg:  # (min-sum takes LLRs and returns bits whatever the symbol width)
             return self._wide_correct(b, erasures)
         if _is_torch(b):
             return self._correct_batch_torch(b, erasures, want_L)
@@ -522,7 +522,7 @@ class rs(cyclic):
 
 class min_sum_decoder(cyclic):
     """The free functions min_sum<R, U>(H, y, tag) of soft_decision.h:220-295 bound to one parity-check matrix
-    (any rows x cols 0/1 matrix, cols <= 256; cc_minsum_create).  correct_batch(), correct(), H(), to_string()
+    (any rows x cols 0/1 matrix, cols <= 2048; cc_minsum_create).  correct_batch(), correct(), H(), to_string()
     and kernel_info() work; there is no code to encode with."""
 
     def __init__(self, H, algorithm=None, stop_rule=capi.STOP_PARITY, device=None):

@@ -372,15 +372,17 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
   if (desc->reserved != 0) return CC_ERR_INVALID_ARGUMENT;
   const bool wide = !matrix_only && desc->q > 8;
   if (wide) {
-    if (is_soft(desc->algorithm) || customH) {
-      set_last_error("min-sum serves matrices of up to 256 columns: q > 8 has hard-decision algorithms only");
+    // min-sum on BCH(2^q - 1, .) for q = 9..11 (cyclic.h:254-267 is width-agnostic): the generic kernel over H's
+    // banded rows, up to 2048 columns; RS has no binary H, a caller-supplied H goes through cc_minsum_create
+    if (customH || (is_soft(desc->algorithm) && (desc->family != CC_FAMILY_BCH || desc->q > 11))) {
+      set_last_error("q > 8: min-sum for BCH codes of up to 2047 columns (q <= 11); custom matrices through cc_minsum_create");
       return CC_ERR_UNSUPPORTED;
     }
     if (desc->coding != CC_CODING_DIVISION) {
       set_last_error("q > 8: division_tag coding only");
       return CC_ERR_UNSUPPORTED;
     }
-    if (desc->t > 32) {
+    if (is_hard(desc->algorithm) && desc->t > 32) {
       set_last_error("hard algorithms: one lane per syndrome, t <= 32");
       return CC_ERR_UNSUPPORTED;
     }
@@ -431,6 +433,11 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
       code->tab.dmin = w.dmin;
       code->tab.mu = w.mu;
       code->tab.step = w.step;
+      // H's first row (h reversed), for min-sum and cc_get_H: 0 / 1 for BCH, anything else makes binary_h false
+      code->tab.binary_h = w.binary_h;
+      code->tab.row0_support = w.row0_support;
+      code->tab.row0.assign(w.row0.size(), 0);
+      for (size_t j = 0; j < w.row0.size(); ++j) code->tab.row0[j] = w.row0[j] ? (w.row0[j] == 1 ? 1 : 2) : 0;
     } else {
       code->field.reset(new Field(desc->q, desc->modular_polynomial));
       code->tab = build_code(*code->field, desc->family, desc->t, desc->mu, desc->step);
@@ -485,9 +492,15 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     } else if (t.n <= 128) {
       g.W = 64;
       g.C = 2;
-    } else {
+    } else if (t.n <= 256) {
       g.W = 64;
       g.C = 4;
+    } else if (t.n <= 2048) {  // the generic kernel's C = 8 / 16 / 32 instantiations: a lane owns columns l + 64 c
+      g.W = 64;
+      g.C = t.n <= 512 ? 8 : t.n <= 1024 ? 16 : 32;
+    } else {
+      set_last_error("min-sum kernels hold one frame per wavefront: at most 2048 columns");
+      return CC_ERR_UNSUPPORTED;
     }
     g.frames_per_wave = 64 / g.W;
     g.KW = static_cast<int>((code->ms_rows + 31) / 32);
@@ -612,8 +625,8 @@ int cc_code_create_with_H(const cc_desc *desc, const uint8_t *H, uint32_t rows, 
 
 int cc_minsum_create(const cc_desc *desc, const uint8_t *H, uint32_t rows, uint32_t cols, cc_code **out) {
   if (!H || rows == 0 || cols == 0) return CC_ERR_INVALID_ARGUMENT;
-  if (cols > 256) {
-    set_last_error("min-sum kernels hold one frame per wavefront: at most 256 columns");
+  if (cols > 2048) {
+    set_last_error("min-sum kernels hold one frame per wavefront: at most 2048 columns");
     return CC_ERR_UNSUPPORTED;
   }
   return code_create_impl(desc, H, rows, cols, out);
@@ -706,7 +719,7 @@ uint32_t cc_q(const cc_code *c) { return c ? c->tab.q : 0; }
 
 int cc_get_H(const cc_code *c, uint8_t *H) {
   if (!c || !H) return CC_ERR_INVALID_ARGUMENT;
-  if (c->wide) return CC_ERR_UNSUPPORTED;
+  if (c->wide && !c->tab.binary_h) return CC_ERR_UNSUPPORTED;  // 16-bit entries: not through the byte getter
   const unsigned n = c->tab.n;
   if (c->matrix_only) {
     std::memcpy(H, c->custom_H.data(), c->custom_H.size());

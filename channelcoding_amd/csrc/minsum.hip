@@ -323,9 +323,15 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   CC_GEO(1, 64, false);
   CC_GEO(2, 64, false);
   CC_GEO(4, 64, false);
+  CC_GEO(8, 64, false);   // up to 512 columns (BCH(511, .) soft decoding, larger caller-supplied matrices)
+  CC_GEO(16, 64, false);  // up to 1024
+  CC_GEO(32, 64, false);  // up to 2048
   CC_GEO(1, 64, true);
   CC_GEO(2, 64, true);
   CC_GEO(4, 64, true);
+  CC_GEO(8, 64, true);
+  CC_GEO(16, 64, true);
+  CC_GEO(32, 64, true);
 #undef CC_GEO
   if (p.gstate) {
     const hipError_t ef = hipFreeAsync(p.gstate, stream);

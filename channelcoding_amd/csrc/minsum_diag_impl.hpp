@@ -347,6 +347,22 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     }
   }
   const int col0 = fl * RC + lam;  // owned columns: lam + LPF c
+  // SINGLE: the frames of a 32-lane group with an odd index keep their cells the other way round, {y, cs'}: the 4-byte
+  // column-sum writes of a half-wave then go to even dwords (even frame) and odd dwords (odd frame) -- 32 banks instead
+  // of 16, so that what is left are the two-way conflicts inside a frame, which a ds_write_b32 hides behind its
+  // register transfer (MI355X_MICROARCH.md, LDS).  Round 2 wrote both frames to the even dwords: four-way, 62 % of the
+  // kernel's LDS cycles were bank conflicts (profiles/r02_pmc_minsum_single_o0_after.txt).  The price is two selects
+  // per edge on a kernel whose vector unit is half idle.
+  const bool oddf = SINGLE && (fl & 1);
+  auto cell_y = [&](float2 v) -> float { return SINGLE ? (oddf ? v.x : v.y) : v.y; };
+  auto cell_cs = [&](float2 v) -> float { return SINGLE ? (oddf ? v.y : v.x) : v.x; };
+  auto make_cell = [&](float cs, float y) -> float2 { return (SINGLE && oddf) ? make_float2(y, cs) : make_float2(cs, y); };
+  const int y_off = (SINGLE && oddf) ? 0 : 4;  // byte offset of y inside a cell
+  int aWR[SINGLE ? D : 1];                      // SINGLE: byte address of the cs' half of a slot's row-0 cell
+  if constexpr (SINGLE) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) aWR[d] = aCY[d] + (oddf ? 4 : 0);
+  }
 
   const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
   unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * FPW + fl;
@@ -440,12 +456,12 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     for (int c = 0; c < CPL; ++c) {
       float y = staged(c) + 0.0f;  // -0.0f -> +0.0f
       if (c == CPL - 1 && lam + LPF * c >= n) y = 0.0f;
-      *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, y);
+      *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_cell(0.0f, y);
     }
     if (er_off != nullptr) {  // cyclic.h:259-262
       for (uint32_t e = er_off[f]; e < er_off[f + 1]; ++e) {
         const int pos = er[e];
-        if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + 4) = 0.0f;
+        if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + y_off) = 0.0f;
       }
     }
     if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
@@ -551,7 +567,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             const int32_t m = __builtin_amdgcn_sbfe(static_cast<int32_t>(keep), sh + D - 1 - d, 1);  // 0 or ~0
             q = u2f(f2u(R[i][d]) & static_cast<uint32_t>(m));
           } else if constexpr (SINGLE) {
-            q = cyq[d].y;
+            q = cell_y(cyq[d]);
             if constexpr (NEEDQ) q = self_correct<VARIANT>(q, 0.0f);
           } else {
             float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
@@ -634,7 +650,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         if constexpr (d < 2 * NLK && (d & 1) == 0 && i >= 1)
           cn[d] = carry_sum[d / 2];  // the head added to this column in row i - 1 and kept the sum
         else if constexpr (SINGLE)
-          cn[d] = cyq[d].x;
+          cn[d] = cell_cs(cyq[d]);
         else
 #ifdef CC_EXP_NO_CNR
           asm volatile("" : "=v"(cn[d]));
@@ -697,7 +713,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         if constexpr (d < 2 * NLK && (d & 1) == 1 && i + 1 < K)
           carry_sum[d / 2] = sum[d];  // the tail of this link continues it in row i + 1
         else if constexpr (SINGLE)
-          *reinterpret_cast<float *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
+          *reinterpret_cast<float *>(cy_base + aWR[slot_base<PG>(d)] + 8 * (i + slot_gap<PG>(d))) = sum[d];
         else
 #ifdef CC_EXP_NO_CNW
           asm volatile("" ::"v"(sum[d]));
@@ -838,13 +854,13 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           const float2 cy = *reinterpret_cast<const float2 *>(cy_base + (col0 + LPF * c) * 8);  // {cs (new), y}
           float y = staged(c) + 0.0f;  // -0.0f -> +0.0f
           if (c == CPL - 1 && lam + LPF * c >= n) y = 0.0f;
-          *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_float2(0.0f, y);
+          *reinterpret_cast<float2 *>(cy_base + (col0 + LPF * c) * 8) = make_cell(0.0f, y);
           emit(c, cy.x + cy.y);
         }
         if (er_off != nullptr) {  // cyclic.h:259-262
           for (uint32_t e = er_off[frame]; e < er_off[frame + 1]; ++e) {
             const int pos = er[e];
-            if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + 4) = 0.0f;
+            if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + y_off) = 0.0f;
           }
         }
         if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });

@@ -240,7 +240,8 @@ def test_minsum_custom_matrix():
 
 @pytest.mark.parametrize("rows,cols,density", [(5, 9, 0.4), (8, 16, 0.3), (12, 31, 0.2), (30, 64, 0.1), (40, 100, 0.08),
                                                (64, 128, 0.05), (33, 129, 0.06), (100, 200, 0.03), (150, 256, 0.03),
-                                               (1, 256, 0.5), (230, 256, 0.02)])
+                                               (1, 256, 0.5), (230, 256, 0.02), (300, 600, 0.012), (40, 257, 0.04),
+                                               (200, 1024, 0.008), (64, 2048, 0.004)])
 def test_min_sum_free_function_any_matrix(rows, cols, density):
     """cc_minsum_create = the free min_sum<R,U>(H, y, tag) (soft_decision.h:220-295) on arbitrary matrices:
     ragged row / column weights, empty rows and columns, widths that are not 2^q - 1."""
@@ -265,6 +266,33 @@ def test_min_sum_free_function_any_matrix(rows, cols, density):
     if len(bad):
         with pytest.raises(cc.decoding_failure):
             cc.min_sum(H, y[bad[0]], TAG[5](15, 0.75, 2.25))
+
+
+@pytest.mark.parametrize("q,t", [(9, 3), (10, 2)])
+def test_minsum_beyond_256_columns(q, t):
+    """cyclic::correct_(soft_decision_tag) is width-agnostic (cyclic.h:254-267) -- on paper: the reference itself cannot
+    instantiate it for q > 8 (H<uint8_t>() converts Element to unsigned char, cyclic.h:349: ill-formed for the 16-bit
+    ef_element; probed with primitive_bch<9, errors<3>>), so the checker is the oracle's min_sum over the explicit
+    matrix the handle reports (parity pinned by the oracle's own pinning, not by a reference run).  BCH(511,484) and
+    BCH(1023,1003) through the generic kernel's C = 8 / 16 instantiations, all-zero and random codewords."""
+    iters = 10
+    rng = np.random.default_rng(90 + q)
+    n = (1 << q) - 1
+    poly = {9: 0x211, 10: 0x409}[q]  # the reference has no default beyond q = 8 (galois.h:57-67)
+    for ov, alpha, beta, rule in ((0, 1.0, 0.0, O2), (1, 0.8, 0.0, O2), (3, 1.0, 0.0, O1), (0, 1.0, 0.0, O0)):
+        code = cc.primitive_bch(q, cc.errors(t), TAG[ov](iters, alpha, beta), stop_rule=rule, modular_polynomial=poly)
+        assert code.n == n and code.kernel_info()["kernel"].startswith("minsum_generic")
+        H = code.H()
+        assert H.shape == (code.k, n) and set(np.unique(H)) <= {0, 1}
+        hard = cc.primitive_bch(q, cc.errors(t), cc.berlekamp_massey_tag(), modular_polynomial=poly)
+        cw = hard.encode_batch(rng.integers(0, 2, (24, hard.l)).astype(np.uint16)).astype(np.uint8)
+        assert not ((H.astype(np.int64) @ cw.T.astype(np.int64)) % 2).any()  # H really is a parity-check matrix of the code
+        cw[:8] = 0
+        y = awgn_llr(rng, cw, code.l / n, 6.0)
+        res = code.correct_batch(y, want_L=True)
+        check(res, *Oracle.minsum_H(H, ov, iters, y, alpha, beta, rule), tag=(q, ov, rule))
+        if rule == O2:
+            assert (res["status"] == 0).sum() >= 4  # the decoder does decode, not only fail like the oracle
 
 
 @pytest.mark.parametrize("q,t,ov,iters", [(8, 18, 4, 10), (8, 30, 0, 10), (8, 31, 3, 5), (7, 14, 4, 10)])
