@@ -150,7 +150,13 @@ struct DiagGeometry {
 const DiagGeometry *diag_geometry(const CodeTables &t);  // nullptr: no diagonal kernel for this code
 std::vector<uint16_t> build_diag_table(const CodeTables &t, int D, int W, int np = 0, const int *gap = nullptr);
 size_t minsum_diag_lds_bytes(const DiagGeometry &g);
+MinSumParams minsum_params(const cc_code *code);
+bool minsum_shortcuts_enabled();
 bool minsum_diag_supported(const cc_code *code);
+// the general diagonal kernel over a compacted batch whose size only the device knows (ctl[1], at most cap frames);
+// ctl: four zeroed device words (MinSumParams::ctl), the producer counts into ctl[1]
+int launch_minsum_diag_compact(const cc_code *code, uint32_t *d_ctl, unsigned cap, const float *d_llr, uint8_t *d_hard,
+                               uint16_t *d_iters, int32_t *d_status, hipStream_t stream);
 std::string minsum_diag_name(const cc_code *code);
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,

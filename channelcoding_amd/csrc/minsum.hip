@@ -279,9 +279,7 @@ int minsum_kernel_info(const cc_code *code, std::string &name, uint32_t &frames_
   return CC_OK;
 }
 
-int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er, const uint32_t *d_er_off,
-                  uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
-  if (B == 0) return CC_OK;
+MinSumParams minsum_params(const cc_code *code) {
   MinSumParams p;
   p.n = static_cast<int>(code->tab.n);
   p.K = static_cast<int>(code->ms_rows);
@@ -293,6 +291,13 @@ int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er,
   p.beta_f = static_cast<float>(code->desc.beta);
   p.beta_d = code->desc.beta;
   p.colmask = code->d_colmask;
+  return p;
+}
+
+int launch_minsum(const cc_code *code, const float *d_llr, const uint16_t *d_er, const uint32_t *d_er_off,
+                  uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  MinSumParams p = minsum_params(code);
 
   if (minsum_diag_supported(code) && !code->force_generic)
     return launch_minsum_diag(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);

@@ -280,13 +280,7 @@ twopass_scatter_kernel(const uint32_t *__restrict__ ctl, unsigned sample, unsign
   }
 }
 
-bool two_pass_enabled() {
-  static const bool v = [] {
-    const char *e = std::getenv("CC_AMD_TWO_PASS");
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
+bool two_pass_enabled() { return minsum_shortcuts_enabled(); }
 
 int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams &p, const float *d_llr, uint8_t *d_hard,
                     uint16_t *d_iters, int32_t *d_status, size_t B, hipStream_t stream) {
@@ -347,6 +341,34 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
 }
 
 }  // namespace
+
+// CC_AMD_TWO_PASS=0: no route that depends on the operating point -- neither two-pass decoding nor the Monte-Carlo
+// pre-check (mc.hip); the tests compare both against the plain route through this switch
+bool minsum_shortcuts_enabled() {
+  static const bool v = [] {
+    const char *e = std::getenv("CC_AMD_TWO_PASS");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
+int launch_minsum_diag_compact(const cc_code *code, uint32_t *d_ctl, unsigned cap, const float *d_llr, uint8_t *d_hard,
+                               uint16_t *d_iters, int32_t *d_status, hipStream_t stream) {
+  const DiagEntry *e = diag_entry(code->tab);
+  if (!e) return CC_ERR_UNSUPPORTED;
+  MinSumParams q = minsum_params(code);
+  q.ctl = d_ctl;  // [2] = [3] = 0: "two passes in effect", [1] = frames in the compact batch
+  q.sample = 1;
+  q.list_cap = cap;
+  q.gate = -1;
+  q.dual = 1;
+  q.llr2 = d_llr;
+  q.hard2 = d_hard;
+  q.iters2 = d_iters;
+  q.status2 = d_status;
+  // (the caller's-batch arguments are never touched: the kernel switches to the compact buffers on the device)
+  return e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, cap, stream);
+}
 
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,

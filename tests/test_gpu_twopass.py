@@ -89,21 +89,30 @@ def test_two_pass_equals_one_pass(tmp_path):
 
 
 def test_monte_carlo_counters_do_not_depend_on_the_route():
-    """cc_mc_run_dev at 8 dB (chunks of 2^20 frames: the two-pass route) against CC_AMD_TWO_PASS=0: same noise (keyed by
-    the global frame index), so every counter -- frames, word / bit errors, failures, iteration histogram -- must agree."""
+    """cc_mc_run_dev with its operating-point shortcuts -- the pre-check route (mc.hip: frames whose channel hard decision
+    is a codeword are counted where the noise is made) from ~5.7 dB on, two-pass decoding below -- against
+    CC_AMD_TWO_PASS=0, the plain route: same noise (keyed by the global frame index), so every counter -- frames, word /
+    bit / channel errors, failures, undetected errors, iteration sum and histogram -- must agree.  All-zero and random
+    codewords, three stop rules, a scaled variant."""
     here = os.path.dirname(os.path.abspath(__file__))
     script = (
         "import sys; sys.path.insert(0, %r)\n"
         "import channelcoding_amd as cc\n"
         "from channelcoding_amd.montecarlo import DeviceBackend\n"
-        "be = DeviceBackend(cc.primitive_bch(8, cc.errors(3), cc.min_sum_tag(20)), random_codewords=False)\n"
-        "print('COUNTERS', [int(x) for x in be.run(8.0, 1234, 0, 1 << 21)])\n" % os.path.dirname(here))
+        "cases = [(cc.min_sum_tag(20), 2, False, 8.0, 1 << 21), (cc.min_sum_tag(20), 2, True, 8.0, 1 << 20),\n"
+        "         (cc.min_sum_tag(20), 2, True, 6.0, 1 << 18), (cc.min_sum_tag(20), 1, False, 7.0, 1 << 18),\n"
+        "         (cc.min_sum_tag(20), 1, True, 7.0, 1 << 17), (cc.min_sum_tag(20), 0, True, 7.0, 1 << 18),\n"
+        "         (cc.normalized_min_sum_tag(10, (8, 10)), 2, True, 6.5, 1 << 18),\n"
+        "         (cc.self_correcting_2_min_sum_tag(10), 2, True, 7.0, 1 << 18), (cc.min_sum_tag(20), 2, False, 4.0, 1 << 17)]\n"
+        "for tag, rule, rnd, ebno, frames in cases:\n"
+        "    be = DeviceBackend(cc.primitive_bch(8, cc.errors(3), tag, stop_rule=rule), random_codewords=rnd)\n"
+        "    print('COUNTERS', [int(x) for x in be.run(ebno, 1234, 77, frames)])\n" % os.path.dirname(here))
     seen = []
     for mode in ("1", "0"):
         out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, CC_AMD_TWO_PASS=mode), capture_output=True,
-                             text=True, timeout=600)
+                             text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-        seen.append([ln for ln in out.stdout.splitlines() if ln.startswith("COUNTERS")][-1])
-    assert seen[0] == seen[1]
-    counters = eval(seen[0].split(" ", 1)[1])
+        seen.append([ln for ln in out.stdout.splitlines() if ln.startswith("COUNTERS")])
+    assert len(seen[0]) == 9 and seen[0] == seen[1], [(a, b) for a, b in zip(*seen) if a != b][:2]
+    counters = eval(seen[0][0].split(" ", 1)[1])
     assert counters[0] == 1 << 21 and 0 < counters[1] < counters[0] // 100  # frames; a few word errors at 8 dB
