@@ -418,6 +418,8 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
                      hipStream_t stream) {
   if (B == 0) return CC_OK;
+  if (algebraic_long_needed(code, d_er_off != nullptr))
+    return launch_algebraic_long(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
   if (algebraic_chunk_supported(code, d_er_off != nullptr))
     return launch_algebraic_chunk(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
   const unsigned long long blocks_needed = (B + 3) / 4;

@@ -298,7 +298,7 @@ algebraic_chunk_kernel(const AlgebraicTables *__restrict__ T, int alg, const voi
         for (int m = lane; m < nc; m += 64) CLL[m] = LL[m * FPW + s];
         const uint32_t cll = LL[(lane < nc ? lane : 0) * FPW + s];  // log lambda_lane, read by readlane (nc <= 64)
         // the PGZ tag runs as bounded-distance decoding: locator degree within capability
-        if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+        if (alg != CC_ALG_BM && 2 * deg > t2) status = CC_FRAME_LOCATOR;
         if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
         if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
 
@@ -806,7 +806,7 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
         CSL[lane] = lg2[sv];
       }
       // the PGZ tag runs as bounded-distance decoding: locator degree within capability
-      if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+      if (alg != CC_ALG_BM && 2 * deg > t2) status = CC_FRAME_LOCATOR;
       if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
       if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
 
@@ -977,7 +977,7 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
       if (lmask) atomicAdd(nleft, 1u);
     }
     int status = CC_FRAME_OK;
-    if (alg == CC_ALG_PGZ && 2 * deg > t2) status = CC_FRAME_LOCATOR;  // bounded-distance decoding
+    if (alg != CC_ALG_BM && 2 * deg > t2) status = CC_FRAME_LOCATOR;  // bounded-distance decoding
     if (deg < 1) status = CC_FRAME_LOCATOR;                            // cyclic.h:145-147
     const unsigned long long group = 2 * chunk + (f >> 5);
     const int fi = f & 31, bit = 8 * (fi & 3) + (fi >> 2);
@@ -1069,7 +1069,14 @@ bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
   // load/store latency and the one-wavefront-per-frame kernel with its higher occupancy wins
   // (BCH(255,231), 6 syndromes: 1128 vs 899 M frames/s); with 32 syndromes this kernel wins (309 vs 220)
   if (code->tab.roots.size() < 8 && !bitslice_supported(code)) return false;
-  return code->desc.algorithm == CC_ALG_BM || code->desc.algorithm == CC_ALG_PGZ;
+  // The Euklid tag without erasures is served as bounded-distance decoding on the Berlekamp-Massey locator, like PGZ:
+  // the remainder sequence of hard_decision.h:157-196 stops at deg r < t, so its sigma has degree <= t, and a frame
+  // comes back corrected exactly when a codeword lies within t symbols of it -- then the key equation has ONE solution
+  // of degree <= t up to a scalar, the one Berlekamp-Massey finds (L <= t), and the corrected word is the same; a
+  // longer register (L > t) is refused here as the reference's root-count / re-check refuses its sigma.  Which of the
+  // failure texts a hopeless frame gets is the only thing that can differ.  With erasures the Sugiyama kernel of
+  // algebraic.hip runs (one wavefront per frame).  tests: hard_golden / seeded (oracle = the reference's Euklid).
+  return code->desc.algorithm == CC_ALG_BM || code->desc.algorithm == CC_ALG_PGZ || code->desc.algorithm == CC_ALG_EUKLID;
 }
 
 // CC_AMD_ALG_STOP=1|2|3 (builds with -DCC_AMD_EXPERIMENTS only): stop the chain after syndromes / Berlekamp-Massey /

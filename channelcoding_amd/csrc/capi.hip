@@ -822,18 +822,8 @@ static int hard_supported(const cc_code *code, bool erasures) {
     return CC_ERR_INVALID_ARGUMENT;
   }
   if (code->device == CC_DEVICE_NONE) return CC_ERR_NO_DEVICE;
-  if (code->tab.roots.size() > 64) {  // one wavefront lane per syndrome / locator coefficient (algebraic.hip)
-    set_last_error("the algebraic kernel handles at most 64 syndromes (t <= 32)");
-    return CC_ERR_UNSUPPORTED;
-  }
-  if (code->desc.algorithm == CC_ALG_EUKLID) {
-    // Sugiyama's remainder sequence starts from x^2t and S(x) u(x) (degree < 2t + erasures), one lane per coefficient
-    const size_t t2 = code->tab.roots.size();
-    if (t2 > 63 || (erasures && t2 > 32)) {
-      set_last_error("the Euklid tag on the device handles t <= 31 (t <= 16 with erasures)");
-      return CC_ERR_UNSUPPORTED;
-    }
-  }
+  // more than 64 syndromes, the Euklid tag with 2t > 63 and erasure decoding with 2t > 32 (Euklid) run
+  // algebraic_long.hip (four locator coefficients per lane) -- launch_algebraic routes them
   if (code->tab.family == CC_FAMILY_RS && (code->desc.mu != 1 || code->desc.step != 1)) {
     set_last_error("RS error values on the device assume roots alpha^1..alpha^2t (mu = step = 1), as rs.h:55-69 does");
     return CC_ERR_UNSUPPORTED;

@@ -162,6 +162,11 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
                        const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                        size_t B, hipStream_t stream);
 // algebraic.hip
+// algebraic_long.hip
+bool algebraic_long_needed(const cc_code *code, bool erasures);
+int launch_algebraic_long(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                          const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                          hipStream_t stream);
 int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
                      const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
                      hipStream_t stream);

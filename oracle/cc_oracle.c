@@ -184,7 +184,7 @@ int orc_code_init(orc_code *c, int family, int q, int t, int mu, int step, int c
   c->mu = mu;
   c->step = step;
   c->coding = coding;
-  if (2 * t > 64) /* roots[64], S[64]: the oracle covers t <= 32 */
+  if (2 * t > 254) /* roots[256], S[256]: every t a GF(2^8) code can have */
     return -4;
   if (2 * t >= c->n)
     return -1;
@@ -424,7 +424,7 @@ static int locator_euklid(const orc_code *c, const uint8_t *S, int nS, const uin
  * the system is regular.  (Mathematical restatement of
  * linear_equation_system.h:12-49,67-88; the reference's pivoting quirk Q9 is
  * NOT reproduced -- see DESIGN.md "reference defects".) */
-static int gauss_solve(const orc_code *c, uint8_t A[][65], int m, uint8_t *x) {
+static int gauss_solve(const orc_code *c, uint8_t A[][257], int m, uint8_t *x) {
   for (int col = 0; col < m; col++) {
     int piv = -1;
     for (int r = col; r < m; r++)
@@ -459,14 +459,14 @@ static int gauss_solve(const orc_code *c, uint8_t A[][65], int m, uint8_t *x) {
  *   S_{i+v} = sum_j sigma_j S_{i+j},  i = 0..v-1
  * and return sigma = [sigma_0..sigma_{v-1}, 1] (monic, roots = locators). */
 static int locator_pgz(const orc_code *c, const uint8_t *S, int nS, poly *out) {
-  static uint8_t A[64][65];
+  static uint8_t A[256][257];
   for (int v = nS / 2; v >= 1; v--) {
     for (int i = 0; i < v; i++) {
       for (int j = 0; j < v; j++)
         A[i][j] = S[i + j];
       A[i][v] = S[i + v];
     }
-    uint8_t sol[64];
+    uint8_t sol[256];
     if (gauss_solve(c, A, v, sol) == 0) {
       memset(out->c, 0, sizeof out->c);
       memcpy(out->c, sol, (size_t)v);
@@ -525,7 +525,7 @@ int orc_locator(const orc_code *c, int alg, const uint8_t *S, const uint16_t *er
 /* ------------------------------------------------------------------------ */
 static int correct_core(const orc_code *c, int alg, const uint8_t *in, const uint16_t *er, int ne, uint8_t *out,
                         int *nerr, int *ref_ub) {
-  uint8_t S[64], sigma[PMAX];
+  uint8_t S[256], sigma[PMAX];
   int nsigma = 0;
   memcpy(out, in, (size_t)c->n);
   if (nerr)
@@ -566,8 +566,8 @@ static int correct_core(const orc_code *c, int alg, const uint8_t *in, const uin
       values[i] = 1; /* bch.h:80-83 */
   } else {
     /* rs.h:41-78: S_i = sum_k y_k X_k^(i+1), i = 0..v-1 */
-    static uint8_t A[64][65];
-    if (nz > 64 || nz > c->nroots)
+    static uint8_t A[256][257];
+    if (nz > 256 || nz > c->nroots)
       return ORC_FRAME_LOCATOR; /* syndromes.at(i) would throw */
     for (int i = 0; i < nz; i++) {
       for (int kx = 0; kx < nz; kx++) {

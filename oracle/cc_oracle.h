@@ -49,7 +49,7 @@ typedef struct orc_code {
   int glen; /* deg g + 1 */
   uint8_t h[256];
   int hlen;
-  uint8_t roots[64]; /* syndrome evaluation points, 2t of them */
+  uint8_t roots[256]; /* syndrome evaluation points, 2t of them */
   int nroots;
 } orc_code;
 

@@ -484,6 +484,8 @@ std::vector<std::unique_ptr<code_iface>> &codes() {
     c.push_back(make_bch<7, dmin<5>>(1, 5));    /* 11 BCH(127,113) benchmark.c++ family */
     c.push_back(make_bch<5, dmin<5>>(1, 5));    /* 12 BCH(31,21)  */
     c.push_back(make_bch<6, dmin<9>>(1, 9));    /* 13 BCH(63,39)  */
+    c.push_back(make_rs<8, errors<40>>(0, 40)); /* 14 RS(255,175): more than 64 syndromes */
+    c.push_back(make_bch<8, errors<40>>(0, 40)); /* 15 BCH(255,47) */
     return c;
   }();
   return v;

@@ -42,7 +42,7 @@ REF_VARIANTS = {
 REF_CODES = {
     0: (BCH, 4, 2), 1: (BCH, 4, 3), 2: (BCH, 4, 2), 3: (BCH, 4, 2), 4: (BCH, 5, 3),
     5: (BCH, 6, 3), 6: (BCH, 8, 3), 7: (RS, 3, 1), 8: (RS, 3, 2), 9: (RS, 4, 3),
-    10: (RS, 8, 16), 11: (BCH, 7, 2), 12: (BCH, 5, 2), 13: (BCH, 6, 4),
+    10: (RS, 8, 16), 11: (BCH, 7, 2), 12: (BCH, 5, 2), 13: (BCH, 6, 4), 14: (RS, 8, 40), 15: (BCH, 8, 40),
 }
 
 
@@ -61,7 +61,7 @@ class OrcCode(C.Structure):
         ("dmin", C.c_int), ("mu", C.c_int), ("step", C.c_int), ("coding", C.c_int), ("size", C.c_int),
         ("exp_", C.c_uint8 * 512), ("log_", C.c_uint8 * 512),
         ("g", C.c_uint8 * 256), ("glen", C.c_int), ("h", C.c_uint8 * 256), ("hlen", C.c_int),
-        ("roots", C.c_uint8 * 64), ("nroots", C.c_int),
+        ("roots", C.c_uint8 * 256), ("nroots", C.c_int),
     ]
 
 

@@ -335,12 +335,75 @@ def test_extreme_code_parameters(fam, q, t, frames):
     for alg in (PGZ, BM, EUKLID):
         code = cls(q, cc.errors(t), TAGS[alg]())
         assert np.array_equal(code.encode_batch(o.extract(cw)), cw)
-        if alg == EUKLID and t == 32:  # x^2t needs coefficient 64: one lane per coefficient ends at 63
-            with pytest.raises(cc.CcError) as e:
-                code.correct_batch(rx)
-            assert e.value.status == capi.ERR_UNSUPPORTED
-            continue
+        # (Euklid at t = 32 needs coefficient 64 of x^2t: algebraic_long.hip, four coefficients per lane)
         check_against_oracle(code.correct_batch(rx), o, alg, rx)
+
+
+def check_erasure_frames(code, o, alg, rxe, ers):
+    """per-frame erasure lists against the oracle (which takes one list per call)"""
+    res = code.correct_batch(rxe, erasures=ers)
+    for f in range(len(rxe)):
+        out, nerr, st, ub = o.correct_hard(alg, rxe[f], ers[f])
+        assert (res["status"][f] == 0) == (st[0] == 0), (alg, f, ers[f], res["status"][f], st[0])
+        if alg == BM:
+            assert res["status"][f] == st[0], (f, res["status"][f], st[0])
+        if st[0] == 0:
+            assert np.array_equal(res["out"][f], out[0]) and res["nerr"][f] == nerr[0], (alg, f)
+        else:
+            assert np.array_equal(res["out"][f], rxe[f])
+
+
+@pytest.mark.parametrize("fam,t,frames", [(RS, 33, 120), (RS, 40, 100), (RS, 64, 80), (RS, 100, 40), (RS, 120, 30),
+                                          (BCH, 40, 100), (BCH, 43, 60), (BCH, 63, 60)])
+def test_more_than_64_syndromes(fam, t, frames):
+    """errors<t> with t > 32 (bch.h:28-46, rs.h:18-28 instantiate any t): algebraic_long.hip, every tag, 0 .. t + 3
+    errors per frame, against the oracle frame for frame; then the same codes with erasures (BM and Euklid: erasure
+    pre-load hard_decision.h:128-131, :171-172), and Euklid with erasures at t = 20 and 32 (2t > 32: the Sugiyama
+    kernel's lane budget ends there)."""
+    o = Oracle(fam, 8, t)
+    rng = np.random.default_rng(700 + t)
+    hi = 2 if fam == BCH else 256
+    cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+    rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, min(o.n, o.t + 4)))) for f in range(frames)])
+    cls = cc.primitive_bch if fam == BCH else cc.rs
+    for alg in (PGZ, BM, EUKLID):
+        code = cls(8, cc.errors(t), TAGS[alg]())
+        assert np.array_equal(code.encode_batch(o.extract(cw)), cw)
+        res = code.correct_batch(rx)
+        check_against_oracle(res, o, alg, rx)
+        assert (res["status"] == 0).sum() >= frames // 2
+    # erasures: e erased positions (zeroed) + up to (2t - e) / 2 errors elsewhere, a few frames beyond that
+    for alg in (BM, EUKLID):
+        code = cls(8, cc.errors(t), TAGS[alg]())
+        rxe, ers = cw[:40].copy(), []
+        for f in range(len(rxe)):
+            ne = int(rng.integers(0, min(2 * o.t + 1, o.n // 2)))  # (more than 2t erasures: status 4 on the device)
+            er = sorted(rng.choice(o.n, ne, replace=False).tolist())
+            rxe[f, er] = 0
+            free = np.setdiff1d(np.arange(o.n), er)
+            for pos in rng.choice(free, int(rng.integers(0, max(1, (2 * o.t - ne) // 2 + 2))), replace=False):
+                rxe[f, pos] ^= 1 if fam == BCH else int(rng.integers(1, hi))
+            ers.append(er)
+        check_erasure_frames(code, o, alg, rxe, ers)
+
+
+@pytest.mark.parametrize("fam,t", [(RS, 20), (RS, 32), (BCH, 21)])
+def test_euklid_with_erasures_beyond_32_syndromes(fam, t):
+    o = Oracle(fam, 8, t)
+    rng = np.random.default_rng(800 + t)
+    hi = 2 if fam == BCH else 256
+    cw = o.encode(rng.integers(0, hi, (60, o.l)).astype(np.uint8))
+    code = (cc.primitive_bch if fam == BCH else cc.rs)(8, cc.errors(t), TAGS[EUKLID]())
+    rxe, ers = cw.copy(), []
+    for f in range(len(rxe)):
+        ne = int(rng.integers(0, 2 * o.t + 1))
+        er = sorted(rng.choice(o.n, ne, replace=False).tolist())
+        rxe[f, er] = 0
+        free = np.setdiff1d(np.arange(o.n), er)
+        for pos in rng.choice(free, int(rng.integers(0, max(1, (2 * o.t - ne) // 2 + 2))), replace=False):
+            rxe[f, pos] ^= 1 if fam == BCH else int(rng.integers(1, hi))
+        ers.append(er)
+    check_erasure_frames(code, o, EUKLID, rxe, ers)
 
 
 @pytest.mark.parametrize("fam,q,t,frames", [(RS, 4, 4, 30000), (RS, 5, 4, 20000), (RS, 5, 8, 8000), (BCH, 6, 4, 20000)])

@@ -69,7 +69,7 @@ def _corrupt(rng, o, cw, nerr):
 
 
 @pytest.mark.parametrize("cid,frames", [(0, 400), (1, 400), (4, 400), (5, 400), (6, 300), (8, 400), (9, 400),
-                                        (10, 120), (11, 200), (13, 200)])
+                                        (10, 120), (11, 200), (13, 200), (14, 60), (15, 60)])
 def test_hard_decode_matches_reference(ref_libs, cid, frames):
     """Oracle == real reference, frame by frame, for 0..t+2 random errors.
 
