@@ -327,6 +327,8 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   char *stg = smem + 4 * WAVE_BYTES + 1024 + wid * (CPL * 256);
   const uint32_t stg_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<size_t>(stg)));
   cbits[threadIdx.x] = colbits[threadIdx.x];
+  __shared__ unsigned wg_next;  // ordinal of the workgroup's next unassigned frame (see take_frame below)
+  if (threadIdx.x == 0) wg_next = 2 * 4 * (64 / LPF);  // every lane group starts with two frames of its own
   __syncthreads();
 
   const int n = p.n;
@@ -365,7 +367,24 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   }
 
   const unsigned long long ngroups = static_cast<unsigned long long>(gridDim.x) * 4 * FPW;
+  // Frames are dealt to WORKGROUPS statically (workgroup b owns the frames b GPW + u + k ngroups, u < GPW = 16 or 32
+  // lane groups, k = 0, 1, ...: the same set as round 2) and to the lane groups of a workgroup DYNAMICALLY: a group that
+  // has finished takes the workgroup's next frame off a counter in LDS.  With a fixed share per group the kernel ended
+  // when the unluckiest of 8192 groups had run its 128 frames -- at 4 dB (1 .. 20 iterations per frame) ~9 % after the
+  // average one, and a wavefront executes its row block as long as ANY of its four groups has work.
+  constexpr unsigned GPW = 4 * FPW;  // lane groups per workgroup
+  auto ordinal_frame = [&](unsigned o) -> unsigned long long {
+    return static_cast<unsigned long long>(blockIdx.x) * GPW + (o % GPW) + static_cast<unsigned long long>(o / GPW) * ngroups;
+  };
+  // the calling lanes are whole groups (those that have just finished): the leader draws, the group reads its draw
+  auto take_frame = [&]() -> unsigned long long {
+    unsigned o = 0;
+    if (lam == 0) o = atomicAdd(&wg_next, 1u);
+    o = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute((lane & ~(LPF - 1)) * 4, static_cast<int>(o)));
+    return ordinal_frame(o);
+  };
   unsigned long long frame = (static_cast<unsigned long long>(blockIdx.x) * 4 + wid) * FPW + fl;
+  unsigned long long nextf = frame + ngroups;  // staged while `frame` is being decoded
   bool active = frame < B;
   unsigned it = 0;
   float R[SINGLE ? 1 : K][SINGLE ? 1 : D];
@@ -477,7 +496,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     stage(frame);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     setup(frame);
-    stage(frame + ngroups);
+    stage(nextf);
   }
 
   while (__any(active)) {
@@ -831,7 +850,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     if (finished && active) {
       const unsigned long long done = frame;
       const unsigned done_it = ok ? it : p.iterations;  // (SINGLE without convergence: Iterations == 1)
-      frame += ngroups;
+      frame = nextf;
       active = frame < B;
       uint8_t *hp = hard + done * n + lam;
       float *Lp = Lout ? Lout + done * n + lam : nullptr;
@@ -888,7 +907,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           if (status_out) status_out[done] = ok ? CC_FRAME_OK : CC_FRAME_NOT_CONVERGED;
         }
       }
-      if (active) stage(frame + ngroups);  // after the reads of STG above have been consumed
+      if (active) {  // after the reads of STG above have been consumed
+        nextf = take_frame();
+        stage(nextf);
+      }
     } else {
       ++it;
     }

@@ -61,7 +61,12 @@ typedef enum cc_algorithm {
                       * as the reference wherever its Gauss elimination is sound; it is not on 1-4 % of decodable
                       * RS frames (linear_equation_system.h:24-35), which this decodes */
   CC_ALG_BM = 1,     /* berlekamp_massey_tag                                        */
-  CC_ALG_EUKLID = 2, /* euklid_tag                                                  */
+  CC_ALG_EUKLID = 2, /* euklid_tag.  With erasures and 2t <= 32: Sugiyama's remainder sequence itself (hard_decision.h:
+                      * 157-196).  Otherwise bounded-distance decoding on the Berlekamp-Massey locator, like PGZ: the
+                      * remainder sequence ends with a locator of degree <= (2t + erasures) / 2, a frame decodes exactly
+                      * when the key equation has its unique solution within that bound, and that is the solution
+                      * Berlekamp-Massey finds -- same corrected words, same frames failing; only WHICH failure text a
+                      * hopeless frame gets may differ */
   CC_ALG_MS = 16,    /* min_sum_tag<It>                                             */
   CC_ALG_NMS = 17,   /* normalized_min_sum_tag<It, ratio>          alpha            */
   CC_ALG_OMS = 18,   /* offset_min_sum_tag<It, ratio>              beta             */
@@ -150,7 +155,7 @@ int cc_get_H_alt(const cc_code *code, uint8_t *H, uint32_t *rows);
  * name a min-sum algorithm; all other members of the new handle (encode, Monte-Carlo, ...) behave as usual. */
 int cc_code_create_with_H(const cc_desc *desc, const uint8_t *H, uint32_t rows, cc_code **out);
 /* The free functions min_sum<R, U>(H, y, tag) of soft_decision.h:220-295 on any rows x cols 0/1 matrix
- * (cols <= 256), no code behind it: only algorithm, iterations, alpha, beta, stop_rule and device of the
+ * (cols <= 2048), no code behind it: only algorithm, iterations, alpha, beta, stop_rule and device of the
  * descriptor are read.  The handle serves cc_correct_soft_batch(_dev), cc_n (= cols), cc_k (= rows), cc_get_H,
  * cc_to_string and cc_kernel_info; every entry point that needs a code returns CC_ERR_INVALID_ARGUMENT. */
 int cc_minsum_create(const cc_desc *desc, const uint8_t *H, uint32_t rows, uint32_t cols, cc_code **out);
