@@ -57,6 +57,16 @@ def measured_traffic(kernel, batch_log2):
     return None
 
 
+def rs_traffic():
+    """HBM bytes of one RS(255,223) decode call of 2^20 frames from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE over
+    the call's kernels, profiles/traffic_rs.json <- profiles/tools/r03_collect.py); None without a measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_rs.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def secondary_workloads(torch, cc, capi, dev):
     """The other single-GPU BASELINE configs, reported next to the headline (not part of `value`):
     configs[1] BCH(63,45) MS<10> at 4 dB, batch 2^16; configs[3] RS(255,223) syndrome + BM + root search +
@@ -148,7 +158,12 @@ def secondary_workloads(torch, cc, capi, dev):
     ms = timed(lambda: lib.cc_correct_hard_batch_dev(rs._h, vp(rx), None, None, vp(outw), vp(ne), vp(st), B, sh))
     ok = bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0
     out["rs255_223_bm_2^20"] = {"frames_per_s": B / (ms * 1e-3), "kernel_ms": ms, "all_frames_corrected": ok,
-                                "achieved_GBs": 518 * B / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_frame": 518}
+                                "achieved_GBs": 518 * B / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_frame": 518,
+                                "traffic": rs_traffic()}
+    rse = cc.rs(8, cc.errors(16), cc.euklid_tag())  # same frames under the Euklid tag (bounded-distance BM on the planes)
+    ms_e = timed(lambda: lib.cc_correct_hard_batch_dev(rse._h, vp(rx), None, None, vp(outw), vp(ne), vp(st), B, sh))
+    out["rs255_223_euklid_2^20"] = {"frames_per_s": B / (ms_e * 1e-3), "kernel_ms": ms_e,
+                                    "all_frames_corrected": bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0}
     enc_ms = timed(lambda: rs.encode_batch(cw[:, rs.k:].contiguous()))
     out["rs255_223_encode_2^20"] = {"frames_per_s": B / (enc_ms * 1e-3), "kernel_ms": enc_ms}
     return out

@@ -18,7 +18,8 @@ for path in args:
         for r in csv.DictReader(f):
             if "ccamd" not in r["Kernel_Name"]:
                 continue
-            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("ccamd::")[1].split("(")[0][:70]
+            # (the whole template argument list: SINGLE / CHAIN sit at its end and name different kernels)
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("ccamd::", "").split("(")[0][:150]
             rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             rows[name]["duration_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
             meta[name] = "grid=%s wg=%s vgpr=%s+%s sgpr=%s lds=%s" % (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"],

@@ -19,7 +19,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def kernel_meta(path):
     with tempfile.TemporaryDirectory() as t:
         fat, co = os.path.join(t, "fat.bin"), os.path.join(t, "dev.co")
-        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path], check=True)
+        r = subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path], capture_output=True)
+        if r.returncode != 0:  # an object without device code
+            return []
         subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
         notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout

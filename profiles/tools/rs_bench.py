@@ -48,5 +48,8 @@ def run(code, hi, maxerr, label):
 
 
 run(cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag()), 256, 16, "RS(255,223) BM e<=16")
+if len(sys.argv) > 2 and sys.argv[2] == "only":  # counter passes: BASELINE configs[3] alone
+    sys.exit(0)
+run(cc.rs(8, cc.errors(16), cc.euklid_tag()), 256, 16, "RS(255,223) EUKLID e<=16")
 run(cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag()), 256, 2, "RS(255,223) BM e<=2")
 run(cc.primitive_bch(8, cc.errors(3), cc.berlekamp_massey_tag()), 2, 3, "BCH(255,231) BM e<=3")
