@@ -427,8 +427,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name.value.decode(), args.batch_log2),
                 "kernel": name.value.decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bytes_per_frame,
                 "measured_copy_GBs": copy_gbs,  # attainable HBM rate on this box (d2d copy, read + write)
-                "note": "path is VALU-issue bound, not HBM bound (SURVEY F4): %.1f min-sum iterations per frame on average"
-                        % mean_iters,
+                "note": "the path is bound by instruction issue (one instruction per ~7 cycles and wavefront at two waves "
+                        "per SIMD, profiles/r03_experiments.md E14), not by HBM (SURVEY F4): %.1f min-sum iterations per "
+                        "frame on average" % mean_iters,
             },
         }
         mix = valu_mix(name.value.decode())

@@ -834,7 +834,7 @@ static int minsum_core(const orc_code *c, const uint8_t *Hin, int k, int n, int 
 /* O(w) restatement: per check node keep min1, min2 (second smallest counting
  * multiplicity), the number of negative and of zero messages; the exclusive
  * sign / minimum of edge j follow from those and q_j itself.  Bit-identical to
- * orc_minsum for finite inputs (asserted by tests/test_oracle_selfcheck.py). */
+ * orc_minsum for finite inputs (asserted by tests/test_oracle_vs_ref.py::test_minsum_matches_reference and test_oracle_golden.py). */
 int orc_minsum_fast(const orc_code *c, int variant, unsigned iterations, double alpha, double beta, int stop_rule,
                     const float *y, uint8_t *b, float *L, unsigned *iter) {
   const int n = c->n, k = c->k;

@@ -59,7 +59,8 @@ def main():
     whole = "--all" in sys.argv
     text = open(path).read().splitlines()
     start = next(i for i, l in enumerate(text) if re.match(r"^_Z\S*:", l) and key in l)
-    end = next(i for i in range(start + 1, len(text)) if text[i].strip().startswith("s_endpgm"))
+    # (the function's end marker, not its first s_endpgm: the kernel has an early exit right behind its prologue)
+    end = next(i for i in range(start + 1, len(text)) if text[i].strip().startswith(".Lfunc_end"))
     body = text[start + 1:end + 1]
     bl = list(blocks(body))
     if whole:
