@@ -1067,12 +1067,12 @@ int cc_decode_soft_batch(const cc_code *code, const float *y, const uint16_t *er
 // coefficient of x^2t (Euklid), of S(x) u(x) (Euklid with erasures, degree < 2t + erasures <= 4t) and of the erasure
 // locator (Berlekamp-Massey pre-load, degree <= 2t)
 static int wide_hard_supported(const cc_code *code, bool erasures) {
-  const size_t t2 = code->tab.roots.size();
+  const size_t t2 = code->tab16.roots.size();  // (a 16-bit handle keeps its vectors in tab16; tab has the scalars only)
   if (code->desc.algorithm == CC_ALG_EUKLID && (t2 > 63 || (erasures && t2 > 32))) {
     set_last_error("the Euklid tag on the device handles t <= 31 (t <= 16 with erasures)");
     return CC_ERR_UNSUPPORTED;
   }
-  if (erasures && t2 > 63) {
+  if (erasures && t2 > 63 && code->desc.algorithm != CC_ALG_PGZ) {  // (the PGZ trials run without erasures)
     set_last_error("erasure decoding on the device handles t <= 31 (one lane per coefficient of the erasure locator)");
     return CC_ERR_UNSUPPORTED;
   }
@@ -1080,13 +1080,7 @@ static int wide_hard_supported(const cc_code *code, bool erasures) {
     set_last_error("The PGZ-Algorithm does not support erasure decoding");  // hard_decision.h:66-68
     return CC_ERR_UNSUPPORTED;
   }
-  if (erasures && code->desc.algorithm == CC_ALG_PGZ) {
-    // capability gap: for BCH the reference runs the two-trial rule of bch.h:97-149, which the byte
-    // path implements (launch_pgz_erasures) and the 16-bit path does not
-    set_last_error("PGZ with erasures on 16-bit symbols is not supported (use the BM or Euklid tag)");
-    return CC_ERR_UNSUPPORTED;
-  }
-  return CC_OK;
+  return CC_OK;  // (BCH with the PGZ tag and erasures: the two-trial rule of bch.h:97-149, launch_wide_pgz_erasures)
 }
 static int wide_ready(const cc_code *code) {
   if (!code->wide) {

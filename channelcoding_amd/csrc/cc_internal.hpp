@@ -182,8 +182,18 @@ bool bitslice_encode_supported(const cc_code *code);
 int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
 int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,
                         uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
+// the object (part) of a geometry that carries a min-sum variant when the geometry is split over `parts` objects
+// (minsum_diag_geos.inc, last column): the two self-correcting variants, the slowest to compile, never share a part
+constexpr int diag_variant_part(int variant, int parts) {
+  const int order = variant == CC_ALG_MS ? 0 : variant == CC_ALG_NMS ? 1 : variant == CC_ALG_OMS ? 2
+                  : variant == CC_ALG_SCMS2 ? 3 : variant == CC_ALG_SCMS1 ? 4 : 5;
+  return order % parts;
+}
+
 // wide.hip
 int launch_wide_correct(const cc_code *code, const uint16_t *d_in, const uint16_t *d_er, const uint32_t *d_off,
+                        uint16_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
+int launch_wide_pgz_erasures(const cc_code *code, const uint16_t *d_in, const uint16_t *d_er, const uint32_t *d_off,
                         uint16_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream);
 int launch_wide_encode(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, hipStream_t stream);
 int launch_wide_extract(const cc_code *code, const uint16_t *d_cw, uint16_t *d_msg, size_t B, hipStream_t stream);

@@ -10,23 +10,34 @@
 namespace ccamd {
 
 // Geometries with a diagonal instantiation: minsum_diag_geos.inc, one object file each.
-#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK)                                                             \
-  int launch_minsum_diag_##NAME(const cc_code *, const MinSumParams &, const float *, const uint16_t *,              \
-                                const uint32_t *, uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
+// (the variants of a geometry are spread over PP objects, part I defines launch_minsum_diag_NAME_pI: diag_variant_part)
+using DiagLaunch = int (*)(const cc_code *, const MinSumParams &, const float *, const uint16_t *, const uint32_t *,
+                           uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
+#define CC_PART_DECL(NAME, I)                                                                                        \
+  int launch_minsum_diag_##NAME##_p##I(const cc_code *, const MinSumParams &, const float *, const uint16_t *,       \
+                                       const uint32_t *, uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
+#define CC_PARTS_1(M, NAME) M(NAME, 0)
+#define CC_PARTS_2(M, NAME) CC_PARTS_1(M, NAME) M(NAME, 1)
+#define CC_PARTS_3(M, NAME) CC_PARTS_2(M, NAME) M(NAME, 2)
+#define CC_PARTS_6(M, NAME) CC_PARTS_3(M, NAME) M(NAME, 3) M(NAME, 4) M(NAME, 5)
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK, PP) CC_PARTS_##PP(CC_PART_DECL, NAME)
 #include "minsum_diag_geos.inc"
 #undef GEO
 namespace {
-using DiagLaunch = int (*)(const cc_code *, const MinSumParams &, const float *, const uint16_t *, const uint32_t *,
-                           uint8_t *, float *, uint16_t *, int32_t *, size_t, hipStream_t);
 struct DiagEntry {
   DiagGeometry geo;
-  DiagLaunch launch;
+  int parts;
+  DiagLaunch launch[6];
 };
+#define CC_PART_REF(NAME, I) &launch_minsum_diag_##NAME##_p##I,
 const DiagEntry kDiagGeometries[] = {
-#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK) {{N, KK, W, DD, LL, CC, SC, LK, {1, 1, 1, 1}}, &launch_minsum_diag_##NAME},
+#define GEO(NAME, N, KK, W, DD, LL, CC, OO, SC, PA, LK, PP)                                                          \
+  {{N, KK, W, DD, LL, CC, SC, LK, {1, 1, 1, 1}}, PP, {CC_PARTS_##PP(CC_PART_REF, NAME)}},
 #include "minsum_diag_geos.inc"
 #undef GEO
 };
+// the object of the geometry that carries the variant of `p`
+DiagLaunch launcher(const DiagEntry *e, const MinSumParams &p) { return e->launch[diag_variant_part(p.variant, e->parts)]; }
 const DiagEntry *diag_entry(const CodeTables &t) {
   for (const DiagEntry &e : kDiagGeometries)
     if (t.n == e.geo.n && t.k == e.geo.k && t.row0_support.size() == e.geo.w) return &e;
@@ -307,12 +318,12 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   q.sample = static_cast<unsigned>(sample * 8 / den);
   if (rc == CC_OK) {  // sample
     q.first_pass = 2;
-    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
+    rc = launcher(e, q)(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
   }
   if (rc == CC_OK) {
     q.first_pass = 1;  // first pass over everything (returns at once unless the sample says so)
     q.gate = 1;
-    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
+    rc = launcher(e, q)(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
   }
   if (rc == CC_OK) {
     const int grid = code->num_cus * 4;
@@ -327,7 +338,7 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
     q.hard2 = hard2;
     q.iters2 = it2;
     q.status2 = st2;
-    rc = e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
+    rc = launcher(e, q)(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, B, stream);
     if (rc == CC_OK)
       hipLaunchKernelGGL(twopass_scatter_kernel, dim3(grid), dim3(256), 0, stream, ctl, su, cu, list, hard2, it2, st2,
                          d_hard, d_iters, d_status, static_cast<int>(n));
@@ -367,7 +378,7 @@ int launch_minsum_diag_compact(const cc_code *code, uint32_t *d_ctl, unsigned ca
   q.iters2 = d_iters;
   q.status2 = d_status;
   // (the caller's-batch arguments are never touched: the kernel switches to the compact buffers on the device)
-  return e->launch(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, cap, stream);
+  return launcher(e, q)(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, cap, stream);
 }
 
 int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
@@ -382,7 +393,7 @@ int launch_minsum_diag(const cc_code *code, const MinSumParams &p, const float *
   if (two_pass_enabled() && plain && p.stop_rule != CC_STOP_AS_SHIPPED && p.iterations >= 2 && d_er_off == nullptr &&
       d_L == nullptr && work >= 1.5e9)
     return launch_two_pass(code, e, p, d_llr, d_hard, d_iters, d_status, B, stream);
-  return e->launch(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
+  return launcher(e, p)(code, p, d_llr, d_er, d_er_off, d_hard, d_L, d_iters, d_status, B, stream);
 }
 
 }  // namespace ccamd

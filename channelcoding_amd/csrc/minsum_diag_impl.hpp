@@ -545,7 +545,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       if constexpr (!PREFETCH) fetch(IR);
       // q, then r, of this row's edges: the message registers, or temporaries when nothing is kept
       // (accessors with literal indices: a reference to R[i] would keep the whole array out of registers)
-      auto wget = [&](auto DD) -> float {
+      [[maybe_unused]] auto wget = [&](auto DD) -> float {
         if constexpr (SINGLE) return Tloc[DD];
         else return R[i][DD];
       };
@@ -681,7 +681,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // back: r from the row's minima and parity, then the column sums (soft_decision.h:101-122, :86-98)
     auto row_back = [&](auto IR, uint32_t m1v, uint32_t m2v, uint32_t sg0, float (&cn)[D]) {
       constexpr int i = decltype(IR)::value;
-      auto wget = [&](auto DD) -> float {
+      [[maybe_unused]] auto wget = [&](auto DD) -> float {
         if constexpr (SINGLE) return Tloc[DD];
         else return R[i][DD];
       };
@@ -707,14 +707,12 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 #endif
         const float hi = u2f(m2v);
         static_for<D>([&](auto DD) {
-          constexpr int d = DD;
           wset(DD, u2f(f2u(__builtin_amdgcn_fmed3f(wget(DD), -hi, hi)) ^ Y));
         });
       } else {
         const uint32_t H1 = f2u(horizontal<VARIANT>(u2f(m1v), p.alpha_f, p.beta_d));
         const uint32_t H2 = f2u(horizontal<VARIANT>(u2f(m2v), p.alpha_f, p.beta_d));
         static_for<D>([&](auto DD) {
-          constexpr int d = DD;
           const uint32_t mag = (__builtin_fabsf(wget(DD)) == u2f(m1v)) ? H2 : H1;
           wset(DD, u2f(xad(mag, sign31, f2u(wget(DD)) & 0x80000000u)));
         });
@@ -922,8 +920,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 
 namespace {
 
+// PARTS / PART: the variants of a geometry are spread over PARTS objects so that the big geometries build in parallel
+// (diag_variant_part in cc_internal.hpp; minsum_diag.hip dispatches); this object instantiates the variants of PART
 template <int K, int D, int LPF, int CPL, int OCC, bool SCMS = false, bool PARTIAL = false, typename PG = PairGaps<>,
-          bool CHAIN = false>
+          bool CHAIN = false, int PARTS = 1, int PART = 0>
 int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float *d_llr, const uint16_t *d_er,
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
@@ -970,7 +970,8 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   // one iteration per frame by construction (stop rule O0, SURVEY F1, or Iterations == 1): the message-free kernel
 #define CC_LAUNCH(V, O)                                                                                            \
   {                                                                                                                \
-    if (single) CC_LAUNCH_S(V, OCC, true) else CC_LAUNCH_S(V, O, false)                                            \
+    if constexpr (diag_variant_part(V, PARTS) != PART) e = hipErrorInvalidValue;                                   \
+    else if (single) CC_LAUNCH_S(V, OCC, true) else CC_LAUNCH_S(V, O, false)                                       \
   }
   switch (p.variant) {
     case CC_ALG_MS: CC_LAUNCH(CC_ALG_MS, OCC) break;

@@ -286,12 +286,99 @@ wide_extract_kernel(const uint16_t *__restrict__ cw, uint16_t *__restrict__ msg,
 int launch_wide_correct(const cc_code *code, const uint16_t *d_in, const uint16_t *d_er, const uint32_t *d_off,
                         uint16_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream) {
   if (B == 0) return CC_OK;
+  if (d_off && code->desc.algorithm == CC_ALG_PGZ)  // BCH only (capi.hip refuses RS): the two-trial rule below
+    return launch_wide_pgz_erasures(code, d_in, d_er, d_off, d_out, d_nerr, d_status, B, stream);
   const unsigned long long blocks = (B + 3) / 4, max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
   hipLaunchKernelGGL(wide_correct_kernel, dim3(static_cast<int>(blocks < max_grid ? blocks : max_grid)), dim3(256), 0,
                      stream, code->wide_dev, code->desc.algorithm, d_in, d_er, d_off, d_out, d_nerr, d_status,
                      static_cast<unsigned long long>(B));
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CC_OK : hip_fail(e, "wide_correct_kernel launch");
+}
+
+// ---- primitive_bch::correct with PGZ and erasures on 16-bit symbols, bch.h:97-149 (width-agnostic there): decode twice
+//      with the erased positions forced to 0 and to 1, keep the result with fewer corrected errors (the first wins
+//      ties).  Same rule as launch_pgz_erasures of the byte path (algebraic.hip); the trials run without erasures. ----
+namespace {
+__global__ void __launch_bounds__(256)
+wide_force_erasures_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ er,
+                           const uint32_t *__restrict__ er_off, uint16_t *__restrict__ in0, uint16_t *__restrict__ in1,
+                           uint32_t n, unsigned long long B) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+    for (uint32_t p = lane; p < n; p += 64) {
+      const uint16_t v = in[f * n + p];
+      in0[f * n + p] = v;
+      in1[f * n + p] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = er_off[f] + lane; e < er_off[f + 1]; e += 64) {  // (the copies above are this wave's own stores)
+      in0[f * n + er[e]] = 0;
+      in1[f * n + er[e]] = 1;
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+wide_select_trial_kernel(const uint16_t *__restrict__ in, const uint32_t *__restrict__ er_off, uint16_t *__restrict__ out0,
+                         int32_t *__restrict__ nerr0, int32_t *__restrict__ st0, const uint16_t *__restrict__ out1,
+                         const int32_t *__restrict__ nerr1, const int32_t *__restrict__ st1, uint32_t n, uint32_t t2,
+                         unsigned long long B) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
+  for (unsigned long long f = wave; f < B; f += nwaves) {
+    const uint32_t ne = er_off[f + 1] - er_off[f];
+    if (ne == 0) continue;  // trial 0 decoded the untouched word: the plain path (bch.h:100-101)
+    const int s0 = st0[f], s1 = st1[f], e0 = nerr0[f], e1 = nerr1[f];
+    int pick, status;
+    if (ne > t2) {
+      pick = -1;
+      status = CC_FRAME_ERASURES;  // bch.h:105-107
+    } else if (s0 != CC_FRAME_OK && s1 != CC_FRAME_OK) {
+      pick = -1;
+      status = CC_FRAME_LOCATOR;  // "Erasure decoding failed."
+    } else {
+      pick = (s0 != CC_FRAME_OK || (s1 == CC_FRAME_OK && e1 < e0)) ? 1 : 0;
+      status = CC_FRAME_OK;
+    }
+    for (uint32_t p = lane; p < n; p += 64) {
+      const uint16_t v = pick < 0 ? in[f * n + p] : (pick == 1 ? out1[f * n + p] : out0[f * n + p]);
+      out0[f * n + p] = v;
+    }
+    if (lane == 0) {
+      nerr0[f] = pick < 0 ? -1 : (pick == 1 ? e1 : e0);
+      st0[f] = status;
+    }
+  }
+}
+}  // namespace
+
+int launch_wide_pgz_erasures(const cc_code *code, const uint16_t *d_in, const uint16_t *d_er, const uint32_t *d_off,
+                             uint16_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B, hipStream_t stream) {
+  if (B == 0) return CC_OK;
+  const size_t n = code->tab.n;
+  uint16_t *in0 = nullptr;
+  int32_t *aux = nullptr;  // nerr0, st0 (when the caller passed none), nerr1, st1
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&in0), 3 * B * n * sizeof(uint16_t), stream));
+  uint16_t *in1 = in0 + B * n, *out1 = in1 + B * n;
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&aux), 4 * B * sizeof(int32_t), stream));
+  int32_t *nerr0 = d_nerr ? d_nerr : aux, *st0 = d_status ? d_status : aux + B, *nerr1 = aux + 2 * B, *st1 = aux + 3 * B;
+  const unsigned long long Bq = B;
+  const int grid = code->num_cus * 8;
+  hipLaunchKernelGGL(wide_force_erasures_kernel, dim3(grid), dim3(256), 0, stream, d_in, d_er, d_off, in0, in1,
+                     static_cast<uint32_t>(n), Bq);
+  int rc = launch_wide_correct(code, in0, nullptr, nullptr, d_out, nerr0, st0, B, stream);
+  if (rc == CC_OK) rc = launch_wide_correct(code, in1, nullptr, nullptr, out1, nerr1, st1, B, stream);
+  if (rc == CC_OK) {
+    hipLaunchKernelGGL(wide_select_trial_kernel, dim3(grid), dim3(256), 0, stream, d_in, d_off, d_out, nerr0, st0, out1,
+                       nerr1, st1, static_cast<uint32_t>(n), code->wide_dev.nroots, Bq);
+    if (hipGetLastError() != hipSuccess) rc = CC_ERR_HIP;
+  }
+  (void)hipFreeAsync(in0, stream);
+  (void)hipFreeAsync(aux, stream);
+  return rc;
 }
 
 int launch_wide_encode(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, hipStream_t stream) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / spill / LDS metadata of the kernels inside a host object or shared library built by hipcc.
 
-    python profiles/tools/kernel_meta.py channelcoding_amd/csrc/build/geo_g255_24.o [name-filter]
+    python profiles/tools/kernel_meta.py channelcoding_amd/csrc/build/geo_g255_24_p0.o [name-filter]
 
 The device code object is the `hipv4-amdgcn-amd-amdhsa--gfx950` bundle of the `.hip_fatbin` section; its
 NT_AMDGPU_METADATA note lists vgpr_count, vgpr_spill_count, private_segment_fixed_size ... per kernel.

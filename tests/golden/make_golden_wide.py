@@ -4,7 +4,8 @@ from /root/reference; this script only runs in the dev container).  Output: test
 
 Codes: wide id 0 = primitive_bch<9, errors<3>> (modular polynomial 0x211), id 1 = rs<10, errors<4>> (0x409).
 Per code: constants (g, h, roots, n/k/l/t/dmin, to_string), encode vectors, and hard decoding with PGZ / BM / Euklid of
-frames carrying 0 .. t + 2 random symbol errors; for BM / Euklid a second set with erasures (positions zeroed)."""
+frames carrying 0 .. t + 2 random symbol errors; for BM / Euklid (and PGZ on the BCH code) a second set with erasures
+(positions zeroed)."""
 import os
 import sys
 
@@ -55,7 +56,8 @@ for wid, (fam, q, t, poly) in RefWide.CODES.items():
     out[p + "rxe"] = rxe
     out[p + "er_off"] = np.concatenate([[0], np.cumsum([len(e) for e in per])]).astype(np.uint32)
     out[p + "er"] = np.array([e for l_ in per for e in l_], np.uint16)
-    for alg, name in ((BM, "bm"), (EUKLID, "euklid")):
+    # (PGZ with erasures exists for BCH only: the two-trial rule of bch.h:97-149; RS throws, hard_decision.h:66-68)
+    for alg, name in ((BM, "bm"), (EUKLID, "euklid")) + (((PGZ, "pgz"),) if fam == 0 else ()):
         o, st, _ = r.correct(alg, rxe, erasures=per)
         out[p + name + "_e_out"], out[p + name + "_e_status"] = o, st
 np.savez_compressed(os.path.join(HERE, "wide.npz"), **out)
