@@ -1133,16 +1133,16 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
                                   int32_t *d_status, size_t B, hipStream_t stream) {
   const int t2 = static_cast<int>(code->tab.roots.size()), nc = t2 + 1;
   const unsigned long long G = (B + 31) / 32, chunks = (B + 63) / 64;
-  const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;  // planes and syndromes are laid out in blocks of 64 groups
+  const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;  // syndromes, locators and root masks are laid out in blocks of 64 groups
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  const size_t plane_bytes = G64 * code->tab.n * 32, synd_bytes = G64 * t2 * 32;
+  const size_t synd_bytes = G64 * t2 * 32;
   const size_t llg_bytes = up(static_cast<size_t>(chunks) * nc * 64 * 2), meta_bytes = up(static_cast<size_t>(chunks) * 64 * 2);
   const size_t mask_bytes = up(static_cast<size_t>(chunks) * 8);
   const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
   CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws),
-                            plane_bytes + synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + 2 * roots_bytes + left_bytes + 256, stream));
-  uint8_t *d_synd = ws + plane_bytes;
+                            synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + 2 * roots_bytes + left_bytes + 256, stream));
+  uint8_t *d_synd = ws;
   uint16_t *d_llg = reinterpret_cast<uint16_t *>(d_synd + synd_bytes);
   uint16_t *d_meta = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d_llg) + llg_bytes);
   unsigned long long *d_mask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(d_meta) + meta_bytes);
@@ -1151,7 +1151,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   unsigned long long *d_left = reinterpret_cast<unsigned long long *>(d_roots + roots_bytes);
   uint32_t *d_nleft = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_left) + left_bytes);
   uint8_t *d_rootsT = reinterpret_cast<uint8_t *>(d_nleft) + 256;
-  int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, ws, d_synd, B, stream);
+  int rc = launch_bitslice_syndromes(code, float_in, d_in, d_out, d_synd, B, stream);
   if (rc == CC_OK) {
     const int dbg_stop = alg_stop_stage();
     const unsigned long long Bq = B, blocks_needed = (chunks + 3) / 4;

@@ -172,6 +172,158 @@ bitslice_syndrome_kernel(const uint4 *__restrict__ planes, uint8_t *__restrict__
   }
 }
 
+// ---------------- decoding: bytes -> planes in LDS -> syndromes, one kernel ----------------
+// The two kernels above exchange the planes through HBM (255 B written + 255 B read per frame) and the syndrome kernel
+// can only fill 2 wavefronts per SIMD (a lane owns a whole group: 2^20 frames are 2048 wavefronts).  Fused form: a
+// workgroup of eight wavefronts takes 8 groups (256 frames, 65 280 contiguous bytes); wavefront w transposes group w
+// into LDS, then -- lane = (group, segment of 32 positions), wavefront w = syndromes 4w+1 .. 4w+4 -- every lane runs the
+// Horner chains of ITS segment, part_s = sum_i b[32 s + i] alpha^(j i), and the eight segments of a group are folded as
+// S_j = sum_s alpha^(32 j s) part_s by a three-level tree over adjacent lanes (multiplications by the constants
+// alpha^(32 j), alpha^(64 j), alpha^(128 j): fixed XOR networks again, 13 % on top of the chains).
+// LDS: word quadruple `half` of the 32 bytes of (position p, group g) at uint4 index ((p & 31) * 2 + half) * 64 +
+// 8 (p >> 5) + (g ^ ((p & 31) >> 2)): the 64 lanes of a syndrome wavefront read 1 KB contiguously, the eight lanes of a
+// transposing wavefront that share a segment write to eight different 16-byte columns.
+constexpr int kFusedGroups = 8, kFusedThreads = 512;
+constexpr size_t kFusedLdsBytes = 32 * 2 * 64 * sizeof(uint4);  // 64 KB: two workgroups per CU, four wavefronts per SIMD
+
+template <int E> __device__ __forceinline__ void times_alpha_e(uint32_t (&x)[8]) {  // x <- x alpha^E
+  const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  horner<E>(x, zero);
+}
+// part += alpha^E * (part of the lane CTRL names: the next segment, two or four further)
+template <int E, int CTRL> __device__ __forceinline__ void fold_segments(uint32_t (&part)[8]) {
+  uint32_t t[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) t[b] = part[b];
+  times_alpha_e<E>(t);
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    part[b] ^= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(t[b]), CTRL, 0xF, 0xF, false));
+}
+template <int J> __device__ __forceinline__ void fold_all(uint32_t (&part)[8]) {  // valid in the lanes of segment 0
+  fold_segments<(32 * J) % 255, 0xB1>(part);   // quad_perm [1,0,3,2]: segment s ^ 1
+  fold_segments<(64 * J) % 255, 0x4E>(part);   // quad_perm [2,3,0,1]: segment s ^ 2
+  fold_segments<(128 * J) % 255, 0x104>(part);  // row_shl:4: segment s + 4
+}
+
+// syndromes J0+1 .. J0+4 of the workgroup's groups: lane = (group lane >> 3, segment lane & 7)
+template <int J0>
+__device__ __forceinline__ void fused_syndromes4(const uint4 *__restrict__ lds, uint8_t *__restrict__ synd,
+                                                 unsigned long long group0, unsigned long long G, int t2) {
+  const int lane = threadIdx.x & 63, g = lane >> 3, seg = lane & 7;
+  uint32_t s[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) s[j][b] = 0;
+  auto all4 = [&](const uint32_t (&r)[8]) {
+    horner<J0 + 1>(s[0], r);
+    horner<J0 + 2>(s[1], r);
+    horner<J0 + 3>(s[2], r);
+    horner<J0 + 4>(s[3], r);
+  };
+  // two positions per trip (the in-place update needs no register copies); i >> 2 is the same for both
+  for (int i = 31; i >= 1; i -= 2) {
+    const int m = 8 * seg + (g ^ (i >> 2));
+    const uint4 a0 = lds[(i * 2) * 64 + m], b0 = lds[(i * 2 + 1) * 64 + m];
+    const uint4 a1 = lds[(i * 2 - 2) * 64 + m], b1 = lds[(i * 2 - 1) * 64 + m];
+    const uint32_t r0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+    const uint32_t r1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
+    all4(r0);
+    all4(r1);
+  }
+  fold_all<J0 + 1>(s[0]);
+  fold_all<J0 + 2>(s[1]);
+  fold_all<J0 + 3>(s[2]);
+  fold_all<J0 + 4>(s[3]);
+  const unsigned long long gg = group0 + g;
+  if (seg != 0 || gg >= G) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (J0 + j >= t2) break;
+    butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
+    uint4 *dst = reinterpret_cast<uint4 *>(synd + (((gg >> 6) * t2 + (J0 + j)) * 64 + (gg & 63)) * 32);
+    dst[0] = make_uint4(s[j][0], s[j][1], s[j][2], s[j][3]);
+    dst[1] = make_uint4(s[j][4], s[j][5], s[j][6], s[j][7]);
+  }
+}
+
+template <bool FLOAT_IN>
+__global__ void __launch_bounds__(kFusedThreads, 4)
+bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ out, uint8_t *__restrict__ synd,
+                               unsigned long long B, unsigned long long G, int n, int t2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fused_smem[];
+  uint4 *lds = reinterpret_cast<uint4 *>(fused_smem);
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long group0 = static_cast<unsigned long long>(blockIdx.x) * kFusedGroups;
+  // positions n .. 255 do not exist: zero planes (n = 255: one position)
+  for (int k = threadIdx.x; k < (256 - n) * 16; k += kFusedThreads) {
+    const int p = n + (k >> 4), i = p & 31;
+    lds[(i * 2 + ((k >> 3) & 1)) * 64 + 8 * (p >> 5) + (k & 7)] = make_uint4(0, 0, 0, 0);
+  }
+  {  // ---- wavefront = group: lane l owns the four positions q .. q+3, q = min(4 l, n - 4) (see bitslice_planes_kernel) ----
+    const unsigned long long g = group0 + wid, f0 = g * 32;
+    const int frames = g >= G ? 0 : static_cast<int>((B - f0) < 32ull ? (B - f0) : 32ull);
+    const int q = 4 * lane < n - 4 ? 4 * lane : n - 4;
+    if (4 * lane < n + 3) {
+      uint32_t v[32];
+      auto fetch = [&](int f) -> uint32_t {
+        const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n) + q;
+        if (FLOAT_IN) {  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
+          const float *x = static_cast<const float *>(in_raw) + at;
+          return (x[0] < 0.0f ? 1u : 0u) | (x[1] < 0.0f ? 0x100u : 0u) | (x[2] < 0.0f ? 0x10000u : 0u) |
+                 (x[3] < 0.0f ? 0x1000000u : 0u);
+        }
+        uint32_t r;
+        __builtin_memcpy(&r, static_cast<const uint8_t *>(in_raw) + at, 4);
+        return r;
+      };
+      if (frames == 32) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f) v[f] = fetch(f);
+#pragma unroll
+        for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+          v[f] = 0;
+          if (f < frames) {
+            v[f] = fetch(f);
+            __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // word k = byte c of the frames {k, 8+k, 16+k, 24+k}
+          const uint32_t sel = 0x0c0c0000u | static_cast<uint32_t>((4 + c) << 8) | static_cast<uint32_t>(c);
+          const uint32_t lo = __builtin_amdgcn_perm(v[8 + k], v[k], sel), hi = __builtin_amdgcn_perm(v[24 + k], v[16 + k], sel);
+          w[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        butterfly(w);  // word b, bit f = bit b of the symbol of frame f
+        const int p = q + c, i = p & 31;
+        uint4 *dst = lds + (i * 2) * 64 + 8 * (p >> 5) + (wid ^ (i >> 2));
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[64] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+    }
+  }
+  __syncthreads();
+  if (4 * wid >= t2) return;
+  switch (wid) {
+    case 0: fused_syndromes4<0>(lds, synd, group0, G, t2); break;
+    case 1: fused_syndromes4<4>(lds, synd, group0, G, t2); break;
+    case 2: fused_syndromes4<8>(lds, synd, group0, G, t2); break;
+    case 3: fused_syndromes4<12>(lds, synd, group0, G, t2); break;
+    case 4: fused_syndromes4<16>(lds, synd, group0, G, t2); break;
+    case 5: fused_syndromes4<20>(lds, synd, group0, G, t2); break;
+    case 6: fused_syndromes4<24>(lds, synd, group0, G, t2); break;
+    default: fused_syndromes4<28>(lds, synd, group0, G, t2); break;
+  }
+}
+
 // ---------------- systematic encoding by evaluation and interpolation ----------------
 // c(x) = a(x) x^k + r(x), deg r < k = 2t, and c(alpha^j) = 0 for j = 1 .. 2t: with E_j = (a x^k)(alpha^j) from the
 // Horner kernel above, r is the polynomial with r(alpha^j) = E_j, i.e. r_i = sum_j W[i][j] E_j with W the inverse of
@@ -451,26 +603,28 @@ bool bitslice_supported(const cc_code *code) {
   return true;
 }
 
-// planes: G64 * n * 32 bytes, synd: G64 * t2 * 32 bytes, G64 = ceil(B / 2048) * 64 groups of 32 frames
-int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, void *d_planes,
-                              uint8_t *d_synd, size_t B, hipStream_t stream) {
+// synd: G64 * t2 * 32 bytes, G64 = ceil(B / 2048) * 64 groups of 32 frames; `out` receives the copy of the words
+int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, uint8_t *d_synd, size_t B,
+                              hipStream_t stream) {
   const int n = static_cast<int>(code->tab.n), t2 = static_cast<int>(code->tab.roots.size());
   const unsigned long long G = (B + 31) / 32, Bq = B;
-  const unsigned long long want = (G + 3) / 4, cap = static_cast<unsigned long long>(code->num_cus) * 32;
-  const int grid = static_cast<int>(want < cap ? want : cap);
-  if (float_in)
-    hipLaunchKernelGGL((bitslice_planes_kernel<true>), dim3(grid), dim3(256), 0, stream, d_in, d_out,
-                       static_cast<uint4 *>(d_planes), Bq, G, n, n, 0);
-  else
-    hipLaunchKernelGGL((bitslice_planes_kernel<false>), dim3(grid), dim3(256), 0, stream, d_in, d_out,
-                       static_cast<uint4 *>(d_planes), Bq, G, n, n, 0);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "bitslice planes kernel launch");
-  const int waves = (t2 + 7) / 8;
-  hipLaunchKernelGGL((bitslice_syndrome_kernel<false>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(64 * waves), 0,
-                     stream, static_cast<const uint4 *>(d_planes), d_synd, G, n, t2, 0);
-  e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "bitslice syndrome kernel launch");
+  const unsigned grid = static_cast<unsigned>((G + kFusedGroups - 1) / kFusedGroups);
+  hipError_t e = hipSuccess;
+  if (float_in) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsBytes));
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<true>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream, d_in,
+                         d_out, d_synd, Bq, G, n, t2);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsBytes));
+    if (e == hipSuccess)
+      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<false>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream, d_in,
+                         d_out, d_synd, Bq, G, n, t2);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "bitslice fused syndrome kernel launch");
   return CC_OK;
 }
 

@@ -176,8 +176,8 @@ int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in,
                            int32_t *d_status, size_t B, hipStream_t stream);
 // bitslice.hip: syndromes of GF(2^8) codes on bit planes (32 frames per register)
 bool bitslice_supported(const cc_code *code);
-int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, void *d_planes,
-                              uint8_t *d_synd, size_t B, hipStream_t stream);
+int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, uint8_t *d_synd, size_t B,
+                              hipStream_t stream);
 bool bitslice_encode_supported(const cc_code *code);
 int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw, size_t B, hipStream_t stream);
 int launch_pgz_erasures(const cc_code *code, const uint8_t *d_in, const uint16_t *d_er, const uint32_t *d_er_off,

@@ -415,7 +415,7 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
                 int random_codewords, float *d_llr, uint8_t *d_sent, uint8_t *d_msg_scratch, hipStream_t stream,
                 unsigned long long *d_counters = nullptr) {
   if (frames == 0) return CC_OK;
-  const int n = static_cast<int>(code->tab.n), l = static_cast<int>(code->tab.l);
+  const int n = static_cast<int>(code->tab.n);
   const float sigma = static_cast<float>(cc_sigma(code, ebno_db));  // normal_distribution<float>(1.0, float(sigma))
   const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
   const uint8_t *sent = nullptr;
