@@ -932,10 +932,10 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
 
 // The correction stage with ONE LANE PER FRAME (64 frames of a chunk per wavefront), everything of a frame in that
 // lane's registers: 16 syndrome logs, 17 locator logs, the 16 omega logs it computes, and its 255-bit root vector
-// (eight words of bitslice_roots_transpose_kernel's output).  The errors of a frame are taken one at a time off the
-// root words (lowest set bit); each costs the two Forney sums with compile-time coefficient indices and unwrapped
-// exponents on the long antilog table.  No cross-lane traffic at all; a trip of the error loop serves up to 64
-// frames.  Frames that need the general treatment -- locator longer than 16, or L != deg (the re-check has to be
+// (eight words of bitslice_roots_transpose_kernel's output).  The errors of a frame are taken off the root words
+// (lowest set bit) into a list, then served one per trip; each costs the two Forney sums with compile-time
+// coefficient indices and unwrapped exponents on the long antilog table.  No cross-lane traffic at all; a trip of
+// the error loop serves up to 64 frames.  Frames that need the general treatment -- locator longer than 16, or L != deg (the re-check has to be
 // evaluated) -- go to chunk_fix_kernel through `left`.
 __global__ void __launch_bounds__(256)
 chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
@@ -945,10 +945,11 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
                   int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   // exl: alpha^i for i < kZ, zero from kZ on; kZ marks a zero operand (log of 0), kZ + kZ still inside the table
   constexpr uint32_t kZ = 8448, kLongSize = 2 * kZ + 64, kN = 255;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256 + 4 * 32 * 64];
   uint8_t *exl = smem;
   uint16_t *lgz = reinterpret_cast<uint16_t *>(smem + kLongSize);  // [256] log, kZ for 0
   uint8_t *lg = smem + kLongSize + 512;                            // [256] plain log table (log 0 = 0)
+  uint8_t *plist = smem + kLongSize + 512 + 256;                   // [wavefront][32][64] error positions, symbols
   for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kZ ? T->exp[i % 255u] : 0;
   lgz[threadIdx.x] = static_cast<uint16_t>(threadIdx.x ? T->log[threadIdx.x] : kZ);
   lg[threadIdx.x] = T->log[threadIdx.x];
@@ -956,6 +957,12 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = lane;
   const int n = T->n, t2 = T->nroots, nc = t2 + 1;
   const bool is_rs = T->family == CC_FAMILY_RS;
+#ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FIXL bits: 1 no load/store of the symbols (16 no load, 32 no store), 2 no Forney sums, 4 no error loop, 8 no omega
+  const int xf = alg >> 8;
+  alg &= 0xFF;
+#else
+  constexpr int xf = 0;
+#endif
 
   const unsigned long long nchunks = (B + 63) / 64;
   const unsigned long long wave = static_cast<unsigned long long>(blockIdx.x) * 4 + wid;
@@ -997,17 +1004,50 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     }
     if (__ballot(fixing) == 0) continue;  // wave-uniform
 
-    uint32_t ll[17], ol[16];  // log lambda_m, log omega_j (kZ for zero)
-    if (is_rs) {
-      uint32_t sl[16];  // log S_j, j < 16 (omega_j, j < deg <= 16, needs no more)
-      const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+    // the error positions of every lane as a list in LDS ([error][lane], bytes): taking them off the root words inside
+    // the Forney loop would cost a trip per (word, error-in-word) of the WORST lane -- about 36 trips for 8 errors
+    // per frame -- instead of one per error of the worst lane
+    uint8_t *PL = plist + wid * (32 * 64);  // [16][64] positions, [16][64] symbols
+    uint32_t have = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) sl[j] = j < t2 ? sb[j * 2048] : 0u;
-#pragma unroll
-      for (int m = 0; m < 17; ++m) {
-        const uint32_t v = m < nc ? llg[(chunk * nc + m) * 64 + f] : kLogZero;
-        ll[m] = v >= kLogZero ? kZ : v;
+    for (int k = 0; k < 8; ++k) {
+      uint32_t w = fixing ? R[k] : 0u;
+      while (__any(w != 0)) {
+        if (w != 0) {
+          PL[have * 64 + lane] = static_cast<uint8_t>(32 * k + __builtin_ctz(w));
+          ++have;
+        }
+        w &= w - 1;
       }
+    }
+    const int emax = (xf & 4) ? 0 : static_cast<int>(wave_umax(have));  // <= 16: a fixing lane has cnt = deg <= 16 roots
+    // All symbols to patch are requested here (four at a time, into LDS), long before the first one is stored: the
+    // memory counter retires in order, so a load issued after a store would wait for that store's acknowledgement on
+    // every trip (measured: 272 us for the kernel with load and store alternating, 150 / 165 us with only one of them).
+    const uint8_t *obase = out + first * n;  // wave-uniform base + 32-bit lane offset
+    uint32_t ll[17], ol[16], sl[16];  // log lambda_m, log omega_j, log S_j (kZ for zero); j < 16: omega_j, j < deg <= 16, needs no more
+    {
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        uint32_t sy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool has = static_cast<uint32_t>(e0 + u) < have;
+          sy[u] = has ? obase[static_cast<uint32_t>(f * n) + PL[(e0 + u) * 64 + lane]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) PL[(16 + e0 + u) * 64 + lane] = static_cast<uint8_t>(sy[u]);
+      }
+      if (is_rs) {
+        const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sl[j] = j < t2 ? sb[j * 2048] : 0u;
+#pragma unroll
+        for (int m = 0; m < 17; ++m) ll[m] = m < nc ? llg[(chunk * nc + m) * 64 + f] : kLogZero;
+      }
+    }
+    if (is_rs) {
+#pragma unroll
+      for (int m = 0; m < 17; ++m) ll[m] = ll[m] >= kLogZero ? kZ : ll[m];
 #pragma unroll
       for (int j = 0; j < 16; ++j) sl[j] = lgz[sl[j]];
       const uint32_t dmax = static_cast<uint32_t>(wave_umax(fixing ? static_cast<uint32_t>(deg) : 0u));
@@ -1015,45 +1055,40 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         uint32_t om = 0;
-        if (static_cast<uint32_t>(j) < dmax) {  // wave-uniform
+        if (static_cast<uint32_t>(j) < dmax && !(xf & 8)) {  // wave-uniform
 #pragma unroll
           for (int m = 0; m <= j; ++m) om ^= exl[ll[m] + sl[j - m]];
         }
         ol[j] = j < deg ? static_cast<uint32_t>(lgz[om]) : kZ;
       }
     }
-    // the errors, one at a time off the root words
+    for (int e = 0; e < emax; ++e) {
+      const bool has = static_cast<uint32_t>(e) < have;
+      const uint32_t p = has ? PL[e * 64 + lane] : 0u;
+      const uint32_t sym = PL[(16 + e) * 64 + lane];
+      uint32_t y = 1;  // bch.h:80-83
+      if (is_rs && !(xf & 2)) {  // Forney, rs.h:41-78
+        const uint32_t xi = p ? kN - p : 0u;  // log X^-1
+        uint32_t x2 = 2 * xi;
+        x2 = umin32(x2, x2 - kN);
+        uint32_t num = 0, den = 0, ee = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t w = fixing ? R[k] : 0u;
-      while (__any(w != 0)) {
-        const bool has = w != 0;
-        const uint32_t p = 32 * k + (has ? __builtin_ctz(w) : 0);
-        w &= w - 1;
-        const uint32_t sym = has ? out[frame * n + p] : 0u;  // requested before the error value is worked out
-        uint32_t y = 1;  // bch.h:80-83
-        if (is_rs) {     // Forney, rs.h:41-78
-          const uint32_t xi = p ? kN - p : 0u;  // log X^-1
-          uint32_t x2 = 2 * xi;
-          x2 = umin32(x2, x2 - kN);
-          uint32_t num = 0, den = 0, e = 0;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {  // omega(X^-1)
-            num ^= exl[ol[j] + e];
-            e += xi;
-          }
-          e = 0;
-#pragma unroll
-          for (int m = 1; m < 17; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
-            den ^= exl[ll[m] + e];
-            e += x2;
-          }
-          y = (num && den) ? exl[lg[num] + kN - lg[den]] : 0u;
+        for (int j = 0; j < 16; ++j) {  // omega(X^-1)
+          num ^= exl[ol[j] + ee];
+          ee += xi;
         }
-        // (an atomic XOR on the surrounding dword instead of the load / store pair was measured slower: 942 vs 1024 M)
-        if (has && y) out[frame * n + p] = static_cast<uint8_t>(sym ^ y);
+        ee = 0;
+#pragma unroll
+        for (int m = 1; m < 17; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+          den ^= exl[ll[m] + ee];
+          ee += x2;
+        }
+        y = (num && den) ? exl[lg[num] + kN - lg[den]] : 0u;
       }
+      // (an atomic XOR on the surrounding dword instead of the load / store pair was measured slower: 942 vs 1024 M)
+      if (has && y && !(xf & 33)) out[frame * n + p] = static_cast<uint8_t>(sym ^ y);
     }
+    __builtin_amdgcn_wave_barrier();  // the list is reused by the next chunk
   }
 }
 
@@ -1086,6 +1121,18 @@ static int alg_stop_stage() {
   static const int v = [] {
     const char *e = std::getenv("CC_AMD_ALG_STOP");
     return e ? std::atoi(e) : 0;
+  }();
+  return v;
+#else
+  return 0;
+#endif
+}
+
+static int fixl_exp() {  // experiment bits of chunk_fixl_kernel (builds with -DCC_AMD_EXPERIMENTS only)
+#ifdef CC_AMD_EXPERIMENTS
+  static const int v = [] {
+    const char *e = std::getenv("CC_EXP_FIXL");
+    return e ? std::atoi(e) << 8 : 0;
   }();
   return v;
 #else
@@ -1186,9 +1233,14 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
       if (four) {  // one lane per frame; what it cannot settle goes on through d_left
         if (launch_bitslice_roots_transpose(d_roots, d_rootsT, B, stream) != CC_OK) e = hipErrorLaunchFailure;
         if (e == hipSuccess) {
-          const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * 6;
+          static const int fixl_per_cu = [] {  // resident workgroups per CU: registers and LDS of the built kernel
+            int v = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, chunk_fixl_kernel, 256, 0) != hipSuccess || v < 1) v = 3;
+            return v;
+          }();
+          const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * fixl_per_cu;
           const int lgrid = static_cast<int>(blocks_needed < lcap ? blocks_needed : lcap);
-          hipLaunchKernelGGL(chunk_fixl_kernel, dim3(lgrid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm, d_synd,
+          hipLaunchKernelGGL(chunk_fixl_kernel, dim3(lgrid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm | fixl_exp(), d_synd,
                              d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_out,
                              d_nerr, d_status, Bq);
           e = hipGetLastError();
