@@ -494,65 +494,103 @@ struct ChienAdvance {
 };
 __constant__ constexpr ChienAdvance kChienAdvance{};
 
-template <int... M>
-__device__ __forceinline__ void chien_step(uint32_t (&T)[kChienCoef][8], std::integer_sequence<int, M...>) {
+// The seventeen terms of a lane are 136 registers -- two wavefronts per SIMD.  So the coefficients are shared out to
+// TWO wavefronts of the same (64 groups, segment): half 0 carries T_0 .. T_8, half 1 carries T_9 .. T_16; each forms
+// its partial sums for two positions, one of them (taking turns) hands its 16 words per lane to the other through
+// LDS, and that one tests the sums and writes the mask words.  Four wavefronts per SIMD.
+template <int M0, int... M>
+__device__ __forceinline__ void chien_step(uint32_t (&T)[9][8], std::integer_sequence<int, M...>) {
   const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  (horner<255 - (M + 1)>(T[M + 1], zero), ...);
+  ((M0 + M == 0 ? (void)0 : horner<(255 - (M0 + M)) % 255>(T[M], zero)), ...);
 }
-__global__ void __launch_bounds__(256)
-bitslice_chien_kernel(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, unsigned long long G) {
-  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned long long blk = blockIdx.x >> 1;
-  const int seg = static_cast<int>(blockIdx.x & 1) * 4 + wid;
+// H = 0: coefficients 0 .. 8, H = 1: coefficients 9 .. 16 (T[8] unused)
+template <int H>
+__device__ __forceinline__ void chien_half(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, uint32_t *__restrict__ xch,
+                                           unsigned long long blk, int seg, unsigned long long G) {
+  constexpr int M0 = H ? 9 : 0, MC = H ? 8 : 9, PB = 2;  // PB positions per batch (four: spills at 128 registers)
+  const int lane = threadIdx.x & 63;
   const unsigned long long g = blk * 64 + lane;
-  if (g >= G) return;
-  uint32_t T[kChienCoef][8];
+  const bool live = g < G;
+  uint32_t T[9][8];
 #pragma unroll
-  for (int m = 0; m < kChienCoef; ++m) {
-    const uint4 *src = lamp + ((blk * kChienCoef + m) * 64 + lane) * 2;
-    const uint4 a = src[0], b = src[1];
-    T[m][0] = a.x, T[m][1] = a.y, T[m][2] = a.z, T[m][3] = a.w;
-    T[m][4] = b.x, T[m][5] = b.y, T[m][6] = b.z, T[m][7] = b.w;
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) T[k][b] = 0;
+    if (k < MC && live) {
+      const uint4 *src = lamp + ((blk * kChienCoef + (M0 + k)) * 64 + lane) * 2;
+      const uint4 a = src[0], c = src[1];
+      T[k][0] = a.x, T[k][1] = a.y, T[k][2] = a.z, T[k][3] = a.w;
+      T[k][4] = c.x, T[k][5] = c.y, T[k][6] = c.z, T[k][7] = c.w;
+    }
   }
-  if (seg != 0) {
+  if (seg != 0) {  // T_m times alpha^(-32 m seg): a masked sum, the constant differs from wavefront to wavefront
 #pragma unroll
-    for (int m = 1; m < kChienCoef; ++m) {
+    for (int k = 0; k < MC; ++k) {
+      if (M0 + k == 0) continue;
       uint32_t o[8];
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const uint32_t row = kChienAdvance.row[seg][m - 1][b];  // wave-uniform
+        const uint32_t row = kChienAdvance.row[seg][M0 + k - 1][b];  // wave-uniform
         uint32_t acc = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc ^= T[m][c] & (0u - ((row >> c) & 1u));
+        for (int c = 0; c < 8; ++c) acc ^= T[k][c] & (0u - ((row >> c) & 1u));
         o[b] = acc;
       }
 #pragma unroll
-      for (int b = 0; b < 8; ++b) T[m][b] = o[b];
+      for (int b = 0; b < 8; ++b) T[k][b] = o[b];
     }
   }
-  using Sixteen = std::make_integer_sequence<int, kChienCoef - 1>;
-  for (int pp = 0; pp < 32; pp += 2) {  // two positions per trip: the in-place update needs no register copies
-    uint32_t out[2];
+  using Mine = std::make_integer_sequence<int, MC>;
+  for (int batch = 0; batch < 32 / PB; ++batch) {
+    uint32_t part[PB][8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      uint32_t nz = 0;
+    for (int u = 0; u < PB; ++u) {
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         uint32_t sum = T[0][b];
 #pragma unroll
-        for (int m = 1; m < kChienCoef; ++m) sum ^= T[m][b];
-        nz |= sum;
+        for (int k = 1; k < MC; ++k) sum ^= T[k][b];
+        part[u][b] = sum;
       }
-      out[u] = ~nz;
-      chien_step(T, Sixteen());
+      chien_step<M0>(T, Mine());
       // keep the steps apart: flattened over several steps the XOR networks grow into sums over every earlier plane
 #pragma unroll
-      for (int m = 1; m < kChienCoef; ++m)
+      for (int k = 0; k < MC; ++k)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(T[m][b]));
+        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(T[k][b]));
     }
-    masks[g * 128 + 16 * seg + (pp >> 1)] = make_uint2(out[0], out[1]);
+    uint32_t *buf = xch + (batch & 1) * (PB * 8 * 64);
+    const bool finisher = (batch & 1) == H;  // wave-uniform
+    if (!finisher) {
+#pragma unroll
+      for (int u = 0; u < PB; ++u)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) buf[(u * 8 + b) * 64 + lane] = part[u][b];
+    }
+    __syncthreads();  // (both segments of the workgroup take the same number of trips)
+    if (finisher) {
+      uint32_t out[PB];
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) nz |= part[u][b] ^ buf[(u * 8 + b) * 64 + lane];
+        out[u] = ~nz;
+      }
+      if (live) masks[g * 128 + 16 * seg + batch] = make_uint2(out[0], out[1]);
+    }
   }
+}
+// workgroup = 64 groups x 2 segments x 2 coefficient halves; a lane writes the 128-byte line of masks[group][256] of its
+// segment, 8 bytes at a time
+__global__ void __launch_bounds__(256, 4)
+bitslice_chien_kernel(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, unsigned long long G) {
+  __shared__ uint32_t xch_all[2][2 * 16 * 64];  // [segment of the workgroup][buffer][word][lane]: 16 KB
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long blk = blockIdx.x >> 2;
+  const int sg = wid >> 1, seg = static_cast<int>(blockIdx.x & 3) * 2 + sg;
+  if (wid & 1) chien_half<1>(lamp, masks, xch_all[sg], blk, seg, G);
+  else chien_half<0>(lamp, masks, xch_all[sg], blk, seg, G);
 }
 
 // masks[group][256] (word = position, bit = frame in plane order) -> rootsT[group][8][32] (word = frame in plane order,
@@ -631,7 +669,7 @@ int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_
 // lamp: G64 * 17 * 32 bytes (chunk_bm_kernel), masks: G64 * 256 words
 int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream) {
   const unsigned long long G = (B + 31) / 32;
-  hipLaunchKernelGGL(bitslice_chien_kernel, dim3(static_cast<unsigned>(2 * ((G + 63) / 64))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bitslice_chien_kernel, dim3(static_cast<unsigned>(4 * ((G + 63) / 64))), dim3(256), 0, stream,
                      static_cast<const uint4 *>(d_lamp), static_cast<uint2 *>(d_masks), G);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice chien kernel launch");
