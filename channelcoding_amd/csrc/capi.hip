@@ -520,7 +520,10 @@ static int code_create_impl(const cc_desc *desc, const uint8_t *customH, uint32_
     pp.location.id = dev;
     hipMemPool_t pool = nullptr;
     if (hipMemPoolCreate(&pool, &pp) == hipSuccess) {
+      // freed workspace stays in the pool for the next call (no allocation after the first call of a size);
+      // CC_AMD_POOL_KEEP_MB caps what a handle keeps -- for processes that hold dozens of decoders
       uint64_t keep = ~0ull;
+      if (const char *mb = std::getenv("CC_AMD_POOL_KEEP_MB")) keep = static_cast<uint64_t>(std::strtoull(mb, nullptr, 10)) << 20;
       if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess)
         code->pool = pool;
       else

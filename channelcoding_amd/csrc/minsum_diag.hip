@@ -248,7 +248,7 @@ size_t minsum_diag_lds_bytes(const DiagGeometry &g) {
 // ---------------- two-pass decoding ----------------
 // At high SNR almost every frame stops after its first iteration, which the message-free kernel runs at about half the
 // cost of the general one (no messages, one column-sum array) -- but only the device knows the operating point.  So:
-//   sample      message-free first pass over the first 4096 frames, counting the frames that did not stop;
+//   sample      message-free first pass over 4096 frames (four runs spread over the batch), counting the frames that did not stop;
 //               two passes if fewer than 1 in 8 of them did not
 //   first pass  (if two passes) message-free kernel over all frames: a frame that stops is written, the others are
 //               appended to a list
@@ -316,9 +316,14 @@ int launch_two_pass(const cc_code *code, const DiagEntry *e, const MinSumParams 
   // two passes iff fewer than 1 in `den` frames of the sample did not stop (the device tests ctl[2] * 8 < q.sample)
   constexpr unsigned den = 8;  // threshold sweep: profiles/r02_experiments.md, E13
   q.sample = static_cast<unsigned>(sample * 8 / den);
-  if (rc == CC_OK) {  // sample
-    q.first_pass = 2;
-    rc = launcher(e, q)(code, q, d_llr, nullptr, nullptr, d_hard, nullptr, d_iters, d_status, sample, stream);
+  // the sample: four runs of 1024 frames spread over the batch (an ordered batch -- SNR sweep, clean frames first --
+  // would fool a leading sample into a first pass that overflows its list)
+  q.first_pass = 2;
+  const size_t runs = B >= 16 * sample ? 4 : 1, per = sample / runs, hop = (B / runs) & ~static_cast<size_t>(63);
+  for (size_t r = 0; r < runs && rc == CC_OK; ++r) {
+    const size_t at = r * hop;
+    rc = launcher(e, q)(code, q, d_llr + at * n, nullptr, nullptr, d_hard + at * n, nullptr, d_iters ? d_iters + at : nullptr,
+                        d_status ? d_status + at : nullptr, per, stream);
   }
   if (rc == CC_OK) {
     q.first_pass = 1;  // first pass over everything (returns at once unless the sample says so)

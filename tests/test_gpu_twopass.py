@@ -27,19 +27,27 @@ def decode_on_device(code, y):
 
 
 def batch(kind, n, rate):
-    rng = np.random.default_rng({"high": 1, "low": 2, "trap": 3}[kind])
+    rng = np.random.default_rng({"high": 1, "low": 2, "trap": 3, "ordered": 4}[kind])
     zeros = np.zeros((FRAMES, n), np.uint8)
     if kind == "high":  # ~5 % of the frames need a second iteration: two passes
         return awgn_llr(rng, zeros, rate, 8.0)
     if kind == "low":   # most frames need many: one pass
         return awgn_llr(rng, zeros, rate, 4.0)
-    y = awgn_llr(rng, zeros, rate, 3.0)  # "trap": a clean sample in front of a noisy batch -> the list overflows
-    y[:4096] = awgn_llr(rng, zeros[:4096], rate, 11.0)
+    if kind == "ordered":  # an SNR sweep in one batch, clean half first: a leading sample would choose two passes
+        y = awgn_llr(rng, zeros, rate, 3.0)
+        y[:FRAMES // 2] = awgn_llr(rng, zeros[:FRAMES // 2], rate, 11.0)
+        return y
+    # "trap": clean frames exactly where the launcher samples (four runs of 1024 frames, launch_two_pass) in a noisy
+    # batch -> two passes are chosen and the list overflows
+    y = awgn_llr(rng, zeros, rate, 3.0)
+    hop = (FRAMES // 4) & ~63
+    for r in range(4):
+        y[r * hop:r * hop + 1024] = awgn_llr(rng, zeros[:1024], rate, 11.0)
     return y
 
 
-@pytest.mark.parametrize("kind", ["high", "low", "trap"])
-@pytest.mark.parametrize("variant,rule", [("ms", O2), ("nms", O1)])
+@pytest.mark.parametrize("kind,variant,rule", [(k, v, r) for k in ("high", "low", "trap") for v, r in (("ms", O2), ("nms", O1))] +
+                         [("ordered", "nms", O1)])
 def test_two_pass_matches_oracle(kind, variant, rule):
     o = Oracle(BCH, 8, 3)
     tag = cc.min_sum_tag(20) if variant == "ms" else cc.normalized_min_sum_tag(20, 0.8)
