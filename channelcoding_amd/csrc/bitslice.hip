@@ -254,6 +254,12 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
                                unsigned long long B, unsigned long long G, int n, int t2) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fused_smem[];
   uint4 *lds = reinterpret_cast<uint4 *>(fused_smem);
+#ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FUSED bits (in n >> 16): 1 no copy of the words, 2 no syndromes (phase timing, E27)
+  const int xs = n >> 16;
+  n &= 0xFFFF;
+#else
+  constexpr int xs = 0;
+#endif
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long group0 = static_cast<unsigned long long>(blockIdx.x) * kFusedGroups;
   // positions n .. 255 do not exist: zero planes (n = 255: one position)
@@ -281,8 +287,10 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
       if (frames == 32) {
 #pragma unroll
         for (int f = 0; f < 32; ++f) v[f] = fetch(f);
+        if (!(xs & 1)) {
 #pragma unroll
-        for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+          for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+        }
       } else {
 #pragma unroll
         for (int f = 0; f < 32; ++f) {
@@ -311,7 +319,7 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
     }
   }
   __syncthreads();
-  if (4 * wid >= t2) return;
+  if (4 * wid >= t2 || (xs & 2)) return;
   switch (wid) {
     case 0: fused_syndromes4<0>(lds, synd, group0, G, t2); break;
     case 1: fused_syndromes4<4>(lds, synd, group0, G, t2); break;
@@ -644,7 +652,11 @@ bool bitslice_supported(const cc_code *code) {
 // synd: G64 * t2 * 32 bytes, G64 = ceil(B / 2048) * 64 groups of 32 frames; `out` receives the copy of the words
 int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, uint8_t *d_synd, size_t B,
                               hipStream_t stream) {
-  const int n = static_cast<int>(code->tab.n), t2 = static_cast<int>(code->tab.roots.size());
+  int n = static_cast<int>(code->tab.n);
+  const int t2 = static_cast<int>(code->tab.roots.size());
+#ifdef CC_AMD_EXPERIMENTS
+  if (const char *x = std::getenv("CC_EXP_FUSED")) n |= std::atoi(x) << 16;
+#endif
   const unsigned long long G = (B + 31) / 32, Bq = B;
   const unsigned grid = static_cast<unsigned>((G + kFusedGroups - 1) / kFusedGroups);
   hipError_t e = hipSuccess;
