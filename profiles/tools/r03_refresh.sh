@@ -12,6 +12,7 @@ python3 profiles/tools/variants_bench.py > $OUT/variants_bench.txt 2>&1
 python3 profiles/tools/mc_bench.py > $OUT/mc_bench.txt 2>&1
 python3 profiles/tools/host_path_bench.py > $OUT/host_path.txt 2>&1
 python3 profiles/tools/rs_bench.py 20 > $OUT/rs_bench.txt 2>&1
+python3 profiles/tools/rs_bench.py 20 erasures > $OUT/rs_erasures.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 stats of the headline command"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_headline -o bench -- \
