@@ -420,7 +420,15 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
   if (B == 0) return CC_OK;
   if (algebraic_long_needed(code, d_er_off != nullptr))
     return launch_algebraic_long(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
-  if (algebraic_chunk_supported(code, d_er_off != nullptr))
+  // The bit-plane chain is seven launches with a floor of 60 .. 100 us per call; below ~4e5 frame-syndromes one
+  // wavefront per frame is faster (profiles/tools/hard_size_sweep.py: RS(255,223) 2^12 frames 32 vs 102 us,
+  // BCH(255,231) 2^14 frames 24 vs 65 us; equal at 2^14 / 2^16 frames)
+  static const size_t planes_min_work = [] {
+    const char *e = std::getenv("CC_AMD_PLANES_MIN_WORK");
+    return e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : static_cast<size_t>(3) << 17;
+  }();
+  const bool small_call = bitslice_supported(code) && B * code->tab.roots.size() < planes_min_work;
+  if (algebraic_chunk_supported(code, d_er_off != nullptr) && !small_call)
     return launch_algebraic_chunk(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
   const unsigned long long blocks_needed = (B + 3) / 4;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;

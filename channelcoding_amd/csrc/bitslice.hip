@@ -640,9 +640,17 @@ bool bitslice_supported(const cc_code *code) {
   const CodeTables &t = code->tab;
   if (t.q != 8 || t.n != 255 || code->field->poly != kPoly) return false;
   const size_t t2 = t.roots.size();
-  // with fewer than 8 syndromes the fixed passes over the batch cost more than the table arithmetic they replace
-  // (profiles/r02_experiments.md, E10)
-  constexpr size_t min_t2 = 8;
+  // Round 2 kept codes with fewer than 8 syndromes on the table kernels (the fixed passes over the batch cost more than
+  // the table arithmetic they replaced, r02 E10); with the fused syndrome kernel and the round-3 corrector the planes
+  // win for every 2t: BCH(255,231) 1.15 -> 2.55 G frames/s, BCH(255,247) 1.89 -> 3.04 G (profiles/r03_experiments.md, E31)
+#ifdef CC_AMD_EXPERIMENTS
+  static const size_t min_t2 = [] {
+    const char *e = std::getenv("CC_EXP_MIN_T2");
+    return e ? static_cast<size_t>(std::atoi(e)) : size_t(2);
+  }();
+#else
+  constexpr size_t min_t2 = 2;
+#endif
   if (t2 < min_t2 || t2 > 32 || t.root_powers.size() != t2) return false;
   for (size_t j = 0; j < t2; ++j)
     if (t.root_powers[j] != j + 1) return false;

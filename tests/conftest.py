@@ -4,6 +4,11 @@ import sys
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+# GF(2^8) hard decoding of n = 255 codes takes the bit-plane chain from ~4e5 frame-syndromes per call on (below that one
+# wavefront per frame is faster); the parity tests want the chain at EVERY size (layout boundaries at 1, 31 .. 4161
+# frames), so the suite runs with the threshold at 0.  tests/test_gpu_bitslice.py::test_small_calls_at_default_settings
+# runs the default in a process of its own.
+os.environ.setdefault("CC_AMD_PLANES_MIN_WORK", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 

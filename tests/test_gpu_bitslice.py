@@ -19,7 +19,8 @@ def make(fam, t, alg=BM):
     return (cc.primitive_bch if fam == BCH else cc.rs)(8, cc.errors(t), TAGS[alg]())
 
 
-@pytest.mark.parametrize("fam,t", [(RS, 16), (RS, 8), (RS, 4), (RS, 5), (BCH, 4), (BCH, 9)])
+@pytest.mark.parametrize("fam,t", [(RS, 16), (RS, 8), (RS, 4), (RS, 5), (RS, 1), (RS, 2), (RS, 3), (BCH, 4), (BCH, 9), (BCH, 1),
+                                   (BCH, 2), (BCH, 3)])
 def test_decode_at_layout_boundaries(fam, t):
     o = Oracle(fam, 8, t)
     code = make(fam, t)
@@ -110,3 +111,37 @@ def test_table_kernels_stay_exact():
     out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, CC_AMD_NO_BITSLICE="1"),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ALT OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_small_calls_at_default_settings():
+    """Without CC_AMD_PLANES_MIN_WORK (the suite sets it to 0, conftest.py) small calls of the bit-plane codes run one
+    wavefront per frame and large ones the chain: same results as the oracle on both sides of the switch."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from checkers import BCH, BM, RS, Oracle\n"
+        "from test_gpu_algebraic import TAGS, check_against_oracle, corrupt\n"
+        "import channelcoding_amd as cc\n"
+        "rng = np.random.default_rng(14)\n"
+        "for fam, t, sizes in ((RS, 16, (1, 65, 2200, 12287, 12288)), (BCH, 3, (33, 65535, 65536))):\n"
+        "    o = Oracle(fam, 8, t)\n"
+        "    code = (cc.primitive_bch if fam == BCH else cc.rs)(8, cc.errors(t), TAGS[BM]())\n"
+        "    hi = 2 if fam == BCH else 256\n"
+        "    for frames in sizes:\n"
+        "        cw = o.encode(rng.integers(0, hi, (min(frames, 700), o.l)).astype(np.uint8))\n"
+        "        rx = np.stack([corrupt(rng, o, cw[f], int(rng.integers(0, t + 3))) for f in range(cw.shape[0])])\n"
+        "        rx = np.tile(rx, ((frames + 699) // 700, 1))[:frames]  # (the oracle sees 700 distinct frames)\n"
+        "        res = code.correct_batch(rx)\n"
+        "        head = {k: v[:rx[:700].shape[0]] for k, v in res.items()}\n"
+        "        check_against_oracle(head, o, BM, rx[:700])\n"
+        "        for k in ('out', 'status', 'nerr'):\n"
+        "            rep = np.tile(head[k], ((frames + 699) // 700,) + (1,) * (head[k].ndim - 1))[:frames]\n"
+        "            assert np.array_equal(res[k], rep), (fam, frames, k)\n"
+        "print('DEFAULT OK')\n" % (here, os.path.dirname(here)))
+    env = {k: v for k, v in os.environ.items() if k != "CC_AMD_PLANES_MIN_WORK"}
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DEFAULT OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
