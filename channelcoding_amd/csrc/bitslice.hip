@@ -250,8 +250,8 @@ __device__ __forceinline__ void fused_syndromes4(const uint4 *__restrict__ lds, 
 
 template <bool FLOAT_IN>
 __global__ void __launch_bounds__(kFusedThreads, 4)
-bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ out, uint8_t *__restrict__ synd,
-                               unsigned long long B, unsigned long long G, int n, int t2) {
+bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__restrict__ synd, unsigned long long B,
+                               unsigned long long G, int n, int t2) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fused_smem[];
   uint4 *lds = reinterpret_cast<uint4 *>(fused_smem);
 #ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FUSED bits (in n >> 16): 1 no copy of the words, 2 no syndromes (phase timing, E27)
@@ -260,6 +260,7 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
 #else
   constexpr int xs = 0;
 #endif
+  const bool copy = static_cast<const void *>(out) != in_raw && !(xs & 1);  // a call that decodes in place has its words there
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long group0 = static_cast<unsigned long long>(blockIdx.x) * kFusedGroups;
   // positions n .. 255 do not exist: zero planes (n = 255: one position)
@@ -287,7 +288,7 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
       if (frames == 32) {
 #pragma unroll
         for (int f = 0; f < 32; ++f) v[f] = fetch(f);
-        if (!(xs & 1)) {
+        if (copy) {
 #pragma unroll
           for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
         }
@@ -297,7 +298,7 @@ bitslice_fused_syndrome_kernel(const void *__restrict__ in_raw, uint8_t *__restr
           v[f] = 0;
           if (f < frames) {
             v[f] = fetch(f);
-            __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+            if (copy) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
           }
         }
       }

@@ -167,7 +167,8 @@ int cc_encode_batch_dev(const cc_code *code, const uint8_t *d_msg, uint8_t *d_cw
 /* ---- hard-decision correct: cyclic::correct / correct_(hard_decision_tag) cyclic.h:207-252,:331-344,
  *      bch.h:85-160.  Erasures in CSR form: frame f owns erasures[erasure_offsets[f] .. erasure_offsets[f+1]);
  *      both pointers NULL = no erasures.  out = corrected word (= hard-decided input when the frame fails),
- *      nerr = number of corrected symbols or -1, status = CC_FRAME_*.  nerr/status may be NULL. ---- */
+ *      nerr = number of corrected symbols or -1, status = CC_FRAME_*.  nerr/status may be NULL.  out may be the
+ *      same buffer as in (decoding in place; the _dev form then skips its copy of the words). ---- */
 int cc_correct_hard_batch(const cc_code *code, const uint8_t *in /* B*n symbols */, const uint16_t *erasures,
                           const uint32_t *erasure_offsets, uint8_t *out /* B*n */, int32_t *nerr, int32_t *status,
                           size_t B);

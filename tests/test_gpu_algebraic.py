@@ -428,3 +428,35 @@ def test_recheck_paths_of_the_chunked_kernel(fam, q, t, frames):
     assert (st == 0).any() and (st == 2).any()
     if fam == RS and t == 4:
         assert (st == 3).any()
+
+
+@pytest.mark.parametrize("fam,q,t,frames", [(RS, 8, 16, 20000), (BCH, 8, 3, 70000), (RS, 8, 16, 300), (BCH, 6, 2, 5000),
+                                            (RS, 6, 8, 5000), (RS, 8, 40, 600)])
+def test_in_place_calls(fam, q, t, frames):
+    """cc_correct_hard_batch_dev with d_out == d_in (the bit-plane chain then skips its copy of the words): the same
+    words, counts and flags as the out-of-place call, on every kernel family (planes, one wavefront per frame, chunks,
+    long locators)."""
+    import ctypes as C
+
+    import torch
+    from channelcoding_amd import capi
+    o = Oracle(fam, q, t)
+    code = (cc.primitive_bch if fam == BCH else cc.rs)(q, cc.errors(t), TAGS[BM]())
+    rng = np.random.default_rng(q * 1000 + t)
+    hi = 2 if fam == BCH else (1 << q)
+    base = o.encode(rng.integers(0, hi, (200, o.l)).astype(np.uint8))
+    rx = np.stack([corrupt(rng, o, base[f], int(rng.integers(0, o.t + 3))) for f in range(200)])
+    rx = np.tile(rx, ((frames + 199) // 200, 1))[:frames]
+    lib = capi.lib()
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    d_in = torch.from_numpy(rx).cuda()
+    d_out = torch.empty_like(d_in)
+    ne = [torch.empty(frames, dtype=torch.int32, device="cuda") for _ in range(2)]
+    st = [torch.empty(frames, dtype=torch.int32, device="cuda") for _ in range(2)]
+    sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cc_correct_hard_batch_dev(code._h, vp(d_in), None, None, vp(d_out), vp(ne[0]), vp(st[0]), frames, sh) == 0
+    assert lib.cc_correct_hard_batch_dev(code._h, vp(d_in), None, None, vp(d_in), vp(ne[1]), vp(st[1]), frames, sh) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d_in, d_out) and torch.equal(ne[0], ne[1]) and torch.equal(st[0], st[1])
+    head = dict(out=d_out[:200].cpu().numpy(), nerr=ne[0][:200].cpu().numpy(), status=st[0][:200].cpu().numpy())
+    check_against_oracle(head, o, BM, rx[:200])
