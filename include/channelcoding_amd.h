@@ -237,7 +237,8 @@ double cc_sigma(const cc_code *code, double ebno_db); /* simulation.c++:83-85 */
 /* ---- fields GF(2^q) with q = 9 .. 15 (galois.h:44-53: "uint16_t allows galois fields up to 2^15"): symbols are
  *      16 bits wide, n = 2^q - 1 <= 32767.  Hard-decision algorithms (PGZ as bounded-distance BM, BM, Euklid), with
  *      erasures; division_tag coding.  The byte entry points above return CC_ERR_UNSUPPORTED on such a handle and
- *      these return it on a q <= 8 handle.  Min-sum (n <= 256 only) and the Monte-Carlo calls do not apply. ---- */
+ *      these return it on a q <= 8 handle.  Min-sum serves BCH codes up to q = 11 (n <= 2047) through the byte entry points
+ *      (bits and LLRs have no symbol width); the Monte-Carlo calls do not apply. ---- */
 int cc_encode_batch_u16(const cc_code *code, const uint16_t *msg /* B*l */, uint16_t *cw /* B*n */, size_t B);
 int cc_encode_batch_u16_dev(const cc_code *code, const uint16_t *d_msg, uint16_t *d_cw, size_t B, void *stream);
 int cc_correct_hard_batch_u16(const cc_code *code, const uint16_t *in /* B*n symbols */, const uint16_t *erasures,

@@ -21,3 +21,17 @@ for rc in (False, True):
         dt = time.perf_counter() - t0
         print("random codewords=%s  %.1f dB: %.2f M frames/s  (%.1f ms for 2^22 frames)  wer=%.4g" % (
             rc, ebno, frames / dt / 1e6, dt * 1e3, int(c[1]) / int(c[0])), flush=True)
+
+# hard decoding in the same pipeline (the reference's simulation runs its hard decoders over the same channel)
+for name, tag in (("BM", cc.berlekamp_massey_tag()), ("PGZ", cc.peterson_gorenstein_zierler_tag())):
+    be = DeviceBackend(cc.primitive_bch(8, cc.errors(3), tag), random_codewords=True)
+    for ebno in (4.0, 8.0):
+        frames = 1 << 22
+        be.run(ebno, 0, 0, 1 << 16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c = be.run(ebno, 0, 0, frames)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("hard %-3s random codewords=True  %.1f dB: %.2f M frames/s  (%.1f ms for 2^22 frames)  wer=%.4g" % (
+            name, ebno, frames / dt / 1e6, dt * 1e3, int(c[1]) / int(c[0])), flush=True)
