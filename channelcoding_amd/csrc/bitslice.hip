@@ -254,13 +254,17 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
                                unsigned long long G, int n, int t2) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fused_smem[];
   uint4 *lds = reinterpret_cast<uint4 *>(fused_smem);
-#ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FUSED bits (in n >> 16): 1 no copy of the words, 2 no syndromes (phase timing, E27)
+#ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FUSED bits (in n >> 16): 1 no copy of the words, 2 no syndromes (phase timing, E27), 4 + 16 k: stagger (E33)
   const int xs = n >> 16;
   n &= 0xFFFF;
 #else
   constexpr int xs = 0;
 #endif
   const bool copy = static_cast<const void *>(out) != in_raw && !(xs & 1);  // a call that decodes in place has its words there
+#ifdef CC_AMD_EXPERIMENTS
+  if ((xs & 4) && (blockIdx.x & 1) && blockIdx.x < 512)  // E33: every other workgroup of the first round starts late
+    for (int i = 0; i < (xs >> 4); ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long group0 = static_cast<unsigned long long>(blockIdx.x) * kFusedGroups;
   // positions n .. 255 do not exist: zero planes (n = 255: one position)
