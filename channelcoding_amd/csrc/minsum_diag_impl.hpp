@@ -356,8 +356,13 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   // kernel's LDS cycles were bank conflicts (profiles/r02_pmc_minsum_single_o0_after.txt).  The price is two selects
   // per edge on a kernel whose vector unit is half idle.
   const bool oddf = SINGLE && (fl & 1);
+#ifndef CC_EXP_O0_B32
   auto cell_y = [&](float2 v) -> float { return SINGLE ? (oddf ? v.x : v.y) : v.y; };
   auto cell_cs = [&](float2 v) -> float { return SINGLE ? (oddf ? v.y : v.x) : v.x; };
+#else  // (E35: the halves are read by their own addresses, already sorted)
+  auto cell_y = [&](float2 v) -> float { return v.y; };
+  auto cell_cs = [&](float2 v) -> float { return v.x; };
+#endif
   auto make_cell = [&](float cs, float y) -> float2 { return (SINGLE && oddf) ? make_float2(y, cs) : make_float2(cs, y); };
   const int y_off = (SINGLE && oddf) ? 0 : 4;  // byte offset of y inside a cell
   int aWR[SINGLE ? D : 1];                      // SINGLE: byte address of the cs' half of a slot's row-0 cell
@@ -533,6 +538,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
 #ifdef CC_EXP_NO_CYR
         asm volatile("" : "=v"(cyq[d].x), "=v"(cyq[d].y));
 #else
+#ifdef CC_EXP_O0_B32
+        if constexpr (SINGLE) {
+          // E35 (measured 4 % SLOWER, experiments only): the two halves of the cell by their own per-lane addresses --
+          // two ds_read_b32 move the same bytes as one ds_read_b64 and save the two selects per edge that sort the
+          // halves out, 20 % of the kernel's VALU instructions; the LDS instructions they add cost more
+          const int at = aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d));
+          cyq[d].x = *reinterpret_cast<const float *>(cy_base + at + (4 - y_off));
+          cyq[d].y = *reinterpret_cast<const float *>(cy_base + at + y_off);
+          return;
+        }
+#endif
         cyq[d] = *reinterpret_cast<const float2 *>(cy_base + aCY[slot_base<PG>(d)] + 8 * (row + slot_gap<PG>(d)));
 #endif
       });
