@@ -442,7 +442,12 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
 #else
   const int dbg_stop = 0;
 #endif
-  const int alg_arg = code->desc.algorithm | (dbg_stop << 8);
+  // The Euklid tag without erasures runs as bounded-distance Berlekamp-Massey (the kernel's PGZ branch), as on the
+  // chunk / plane / long paths: the same corrected words and the same failing frames as the remainder sequence of
+  // hard_decision.h:157-196 (argument in algebraic_chunk_supported, algebraic_chunk.hip); Sugiyama itself runs where
+  // the erasure locator enters the start polynomials.
+  const int alg_eff = (code->desc.algorithm == CC_ALG_EUKLID && d_er_off == nullptr) ? CC_ALG_PGZ : code->desc.algorithm;
+  const int alg_arg = alg_eff | (dbg_stop << 8);
   if (float_in)
     hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg, d_in,
                        d_er, d_er_off, d_out, d_nerr, d_status, Bq);
