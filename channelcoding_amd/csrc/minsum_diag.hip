@@ -221,7 +221,7 @@ bool minsum_diag_supported(const cc_code *code) {
   const DiagGeometry *geo = diag_geometry(code->tab);
   if (!geo) return false;
   if (alg == CC_ALG_SCMS1) return true;        // two bits per edge: every geometry
-  if (alg == CC_ALG_SCMS2) return geo->scms;  // q itself: where 2 K D registers fit
+  if (alg == CC_ALG_SCMS2) return geo->scms;  // (every geometry of minsum_diag_geos.inc since the q-only form, E38)
   if (alg != CC_ALG_MS && alg != CC_ALG_NMS && alg != CC_ALG_OMS && alg != CC_ALG_2DNMS) return false;
   if (alg == CC_ALG_OMS && !(code->desc.beta >= 0.0)) return false;
   const float a = static_cast<float>(code->desc.alpha);

@@ -392,17 +392,31 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
   unsigned long long nextf = frame + ngroups;  // staged while `frame` is being decoded
   bool active = frame < B;
   unsigned it = 0;
-  float R[SINGLE ? 1 : K][SINGLE ? 1 : D];
-  // self-correcting variants keep the previous variable->check message of every edge as well (instantiated
-  // only where 2 K D registers fit, see kDiagGeometries)
+  // SCMS2 (soft_decision.h:273-282) needs the previous variable->check message q of every edge AS A VALUE
+  // (0.5 (t + q_old)).  Keeping q next to the check->variable message r doubles the message registers (one wavefront
+  // per SIMD on the headline geometry: 33 M frames/s).  But r is a function of q and of three numbers of its ROW --
+  // r = +-(|q| == m1 ? m2 : m1), sign = row parity x sign(q): the two instructions of row_back -- so the kernel keeps q
+  // only, parks (m1, m2 | parity) of every row in LDS (8 bytes per row and frame) and works r out again where the next
+  // iteration subtracts it: 2 instructions per edge more, half the registers, the occupancy of plain min-sum (E38).
   constexpr bool NEEDQ = (VARIANT == CC_ALG_SCMS1 || VARIANT == CC_ALG_SCMS2);
-  constexpr bool KEEPQ = VARIANT == CC_ALG_SCMS2 && !SINGLE;
+  // It pays where q AND r would not fit the register budget of plain min-sum (measured over the registry's codes, E38:
+  // BCH(255,231) SCMS2 33 -> 46 M frames/s, BCH(127,113) 78 -> 94; with room for both arrays the two extra
+  // instructions per edge cost 10 .. 30 %), and it is what lets the two geometries with >= 196 message registers run
+  // SCMS2 at all.  SCMS1 needs only two BITS of q_old and keeps them in bit words next to r (BITS1 below) -- except on
+  // the headline geometry, where those words pushed 48 registers to scratch: there it keeps q too (38.6 -> 45 M).
+  constexpr bool QONLY = !SINGLE && ((VARIANT == CC_ALG_SCMS2 && 2 * K * D + 64 > 256) ||
+                                     (VARIANT == CC_ALG_SCMS1 && K * D >= 160 && OCC >= 2));
+  constexpr bool KEEPQ = (VARIANT == CC_ALG_SCMS2 && !SINGLE) || QONLY;
+  float R[(SINGLE || QONLY) ? 1 : K][(SINGLE || QONLY) ? 1 : D];
   float Q[KEEPQ ? K : 1][KEEPQ ? D : 1];
+  __shared__ uint2 row_state[QONLY ? 4 * FPW * K : 1];  // [lane group of the workgroup][row] = {m1, m2 | parity << 31}
+  uint2 *const my_rows = row_state + (QONLY ? (wid * FPW + fl) * K : 0);
+  uint2 rsq = make_uint2(0u, 0u);  // the state of the row in hand, fetched with its operands
   // SCMS1 (soft_decision.h:261-266) needs two bits of the previous variable->check message of an edge, not the
   // message: its sign S and whether it was zero Z -- q = (Z or S == sign(t)) ? t : 0 (for t = +-0 both arms are
   // zero, so signum(t) need not be looked at).  Bit field of row i: D bits at RPW-row words, edge d at bit
   // D - 1 - d of the field (the order v_alignbit / v_addc shift them in); updated in place row by row.
-  constexpr bool BITS1 = VARIANT == CC_ALG_SCMS1 && !SINGLE;
+  constexpr bool BITS1 = VARIANT == CC_ALG_SCMS1 && !SINGLE && !QONLY;
   constexpr int RPW = 32 / D;                  // rows per 32-bit word
   constexpr int NW = (K + RPW - 1) / RPW;      // words per lane
   uint32_t SW[BITS1 ? NW : 1], ZW[BITS1 ? NW : 1];
@@ -488,8 +502,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
         if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + y_off) = 0.0f;
       }
     }
-    if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+    if constexpr (!SINGLE && !QONLY) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
     if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+    if constexpr (QONLY)
+      for (int r = lam; r < K; r += LPF) my_rows[r] = make_uint2(0u, 0u);  // r_old = 0 everywhere
     if constexpr (BITS1) static_for<NW>([&](auto Wd) { SW[Wd] = 0u; ZW[Wd] = 0xFFFFFFFFu; });  // q_old = 0 everywhere
   };
 
@@ -526,6 +542,7 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     float carry_sum[NLK ? NLK : 1];  // the head's running column sum of the row before
     auto fetch = [&](auto IC) {
       constexpr int row = decltype(IC)::value;
+      if constexpr (QONLY) rsq = my_rows[row];
       static_for<D>([&](auto DD) {
         constexpr int d = DD;
         if constexpr (d < 2 * NLK && (d & 1) == 0 && row >= 1) {
@@ -563,12 +580,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
       // (accessors with literal indices: a reference to R[i] would keep the whole array out of registers)
       [[maybe_unused]] auto wget = [&](auto DD) -> float {
         if constexpr (SINGLE) return Tloc[DD];
+        else if constexpr (QONLY) return Q[i][DD];
         else return R[i][DD];
       };
       auto wset = [&](auto DD, float v) {
         if constexpr (SINGLE) Tloc[DD] = v;
-        else R[i][DD] = v;
+        else if constexpr (!QONLY) R[i][DD] = v;  // (QONLY: q already sits in Q[i][d])
       };
+      // QONLY: last iteration's r of this row from its q and the row's parked (m1, m2, parity), exactly as row_back made it
+      [[maybe_unused]] const float old_hi = u2f(rsq.y & 0x7FFFFFFFu);
+      [[maybe_unused]] uint32_t old_Y = (rsq.x ^ rsq.y);  // (m1 ^ m2) | parity << 31: m1 has a clear sign bit
+      if constexpr (QONLY) asm volatile("" : "+v"(old_Y));
       {
         // with one diagonal per lane the lane's second minimum is "none": numeric_limits<float>::max(), the
         // starting value of the reference's own search (soft_decision.h:110); with D >= 2 both are overwritten
@@ -605,10 +627,23 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             q = cell_y(cyq[d]);
             if constexpr (NEEDQ) q = self_correct<VARIANT>(q, 0.0f);
           } else {
-            float e = cyq[d].x - R[i][d];                                       // soft_decision.h:135
+            float r_old;
+            if constexpr (QONLY) r_old = u2f(f2u(__builtin_amdgcn_fmed3f(Q[i][d], -old_hi, old_hi)) ^ old_Y);
+            else r_old = R[i][d];
+            float e = cyq[d].x - r_old;                                         // soft_decision.h:135
             if constexpr (VARIANT == CC_ALG_2DNMS) e = __fmul_rn(p.beta_f, e);  // :215-218
             q = e + cyq[d].y;                                                   // :136,:207-209
-            if constexpr (KEEPQ) {
+            if constexpr (QONLY && VARIANT == CC_ALG_SCMS1) {
+              // soft_decision.h:261-266 without compares: keep t iff q_old is zero or their sign bits agree.  Neither t
+              // nor a kept q is ever -0.0f here (t = e + y with y canonicalised on load; a dropped q is +0.0f), so
+              // "q_old == 0" is "its bits are 0" and signum(t) = 0 lands on the right arm by its sign bit alone.
+              const uint32_t so = f2u(Q[i][d]), st = f2u(q);
+              const int differ = static_cast<int>(so ^ st) >> 31;   // all ones: the sign bits differ
+              const uint32_t zero_old = umin32(so, 1u) - 1u;        // all ones: q_old == 0
+              q = u2f(static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(static_cast<int>(st), static_cast<int>(zero_old), differ,
+                                                                        0xD0)));  // t & (zero_old | ~differ)
+              Q[i][d] = q;
+            } else if constexpr (KEEPQ) {
               q = self_correct<VARIANT>(q, Q[i][d]);
               Q[i][d] = q;
             }
@@ -697,12 +732,17 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
     // back: r from the row's minima and parity, then the column sums (soft_decision.h:101-122, :86-98)
     auto row_back = [&](auto IR, uint32_t m1v, uint32_t m2v, uint32_t sg0, float (&cn)[D]) {
       constexpr int i = decltype(IR)::value;
+      float rt[QONLY ? D : 1];  // QONLY: this row's r, used for the column sums and dropped
+      bool made = false;        // (wget returns q until the row's r has been made)
+      (void)made;
       [[maybe_unused]] auto wget = [&](auto DD) -> float {
         if constexpr (SINGLE) return Tloc[DD];
+        else if constexpr (QONLY) return made ? rt[DD] : Q[i][DD];
         else return R[i][DD];
       };
       auto wset = [&](auto DD, float v) {
         if constexpr (SINGLE) Tloc[DD] = v;
+        else if constexpr (QONLY) rt[DD] = v;
         else R[i][DD] = v;
       };
       // the parity leaves the last DPP stage in a register of its own: folded into the mask below, the compiler
@@ -732,6 +772,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
           const uint32_t mag = (__builtin_fabsf(wget(DD)) == u2f(m1v)) ? H2 : H1;
           wset(DD, u2f(xad(mag, sign31, f2u(wget(DD)) & 0x80000000u)));
         });
+      }
+      made = true;
+      if constexpr (QONLY) {  // park the row's minima and parity for the next iteration's front (one lane per frame writes)
+        if (lam == 0) my_rows[i] = make_uint2(m1v, m2v | sign31);
       }
       // column sums: all D additions behind ONE wait (the last-issued read first: once it has arrived the others
       // have too, LDS returns in order), then the D stores -- instead of a wait in front of every addition
@@ -896,8 +940,10 @@ minsum_diag_kernel(MinSumParams p, const uint16_t *__restrict__ diag_s, const ui
             if ((pos & (LPF - 1)) == lam) *reinterpret_cast<float *>(cy_base + (fl * RC + pos) * 8 + y_off) = 0.0f;
           }
         }
-        if constexpr (!SINGLE) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
+        if constexpr (!SINGLE && !QONLY) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { R[I][Dd] = 0.0f; }); });
         if constexpr (KEEPQ) static_for<K>([&](auto I) { static_for<D>([&](auto Dd) { Q[I][Dd] = 0.0f; }); });
+        if constexpr (QONLY)
+          for (int r = lam; r < K; r += LPF) my_rows[r] = make_uint2(0u, 0u);
         if constexpr (BITS1) static_for<NW>([&](auto Wd) { SW[Wd] = 0u; ZW[Wd] = 0xFFFFFFFFu; });
         it = 0;
       } else {
@@ -944,9 +990,11 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
                          const uint32_t *d_er_off, uint8_t *d_hard, float *d_L, uint16_t *d_iters, int32_t *d_status,
                          size_t B, hipStream_t stream) {
   constexpr int RB = 1;  // rows per reduction batch (the row-pipelined body reduces one row at a time)
-  // the self-correcting variants carry K D more registers per lane: their own occupancy target (beyond 256
-  // registers a single wave per SIMD spills q to the accumulation registers: still far ahead of the generic kernel)
-  constexpr int OCC_S = (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : (2 * K * D + 64 <= 256) ? 2 : 1;
+  // SCMS2 carries K D more registers per lane (q next to r) and its own occupancy target -- unless that would leave a
+  // single wave per SIMD: then the kernel keeps q INSTEAD of r (QONLY in the kernel: r is worked out again from q and
+  // the row's parked minima) and runs at the occupancy of plain min-sum, plus 8 bytes of LDS per row and frame
+  constexpr bool Q_ONLY_2 = 2 * K * D + 64 > 256, Q_ONLY_1 = K * D >= 160 && OCC >= 2;
+  constexpr int OCC_S = Q_ONLY_2 ? OCC : (2 * K * D + 64 <= 128) ? 4 : (2 * K * D + 64 <= 168) ? 3 : 2;
   constexpr int FPW = 64 / LPF;
   if (!(code->tab.n > static_cast<unsigned>(LPF * (CPL - 1)) && code->tab.n <= static_cast<unsigned>(LPF * CPL))) {
     set_last_error("minsum_diag: only the last owned column of a lane may lie beyond the frame");
@@ -956,8 +1004,9 @@ int launch_diag_geometry(const cc_code *code, const MinSumParams &p, const float
   const size_t lds = minsum_diag_lds_bytes(g);
   const unsigned long long blocks_needed = (B + 4 * FPW - 1) / (4 * FPW);
   unsigned long long per_cu = (160 * 1024) / lds;  // resident workgroups: LDS, then the register budget (OCC waves per SIMD)
-  // SCMS2 keeps q in K D more registers (OCC_S); SCMS1 keeps two bits per edge and runs at the occupancy of plain MS
   const unsigned long long occ = p.variant == CC_ALG_SCMS2 ? static_cast<unsigned long long>(OCC_S) : OCC;
+  if ((p.variant == CC_ALG_SCMS2 && Q_ONLY_2) || (p.variant == CC_ALG_SCMS1 && Q_ONLY_1))
+    per_cu = (160 * 1024) / (lds + 4 * FPW * K * sizeof(uint2));  // + row_state (static)
   if (per_cu > occ) per_cu = occ;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * per_cu;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);

@@ -33,7 +33,10 @@ def timed(fn, reps=3):
 print("%-22s %-44s %10s %8s %8s" % ("code", "kernel", "Mframes/s", "GB/s", "iters"))
 for q, ts in ((5, (1, 2, 3, 4)), (6, (1, 2, 3, 4)), (7, (1, 2, 3, 4)), (8, (1, 2, 3, 4))):
     for t in ts:
-        for tag in (cc.min_sum_tag(50), cc.self_correcting_1_min_sum_tag(50)):
+        tags = (cc.min_sum_tag(50), cc.self_correcting_1_min_sum_tag(50))
+        if len(sys.argv) > 1 and sys.argv[1] == "scms":  # the two self-correcting variants only
+            tags = (cc.self_correcting_1_min_sum_tag(50), cc.self_correcting_2_min_sum_tag(50))
+        for tag in tags:
             code = cc.primitive_bch(q, cc.errors(t), tag)
             n = code.n
             y = torch.empty((B, n), dtype=torch.float32, device=dev).normal_(1.0, float(code.sigma(4.0)), generator=g)
