@@ -429,7 +429,7 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
   }();
   const bool small_call = bitslice_supported(code) && B * code->tab.roots.size() < planes_min_work;
   if (algebraic_chunk_supported(code, d_er_off != nullptr) && !small_call)
-    return launch_algebraic_chunk(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
+    return launch_algebraic_chunk(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
   const unsigned long long blocks_needed = (B + 3) / 4;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);

@@ -12,7 +12,7 @@
 //                           table gather and an XOR, with no zero tests
 //   C  root search, error values, re-check, store: one frame at a time again (parallel over positions)
 //
-// Erasures and the Euklid tag stay on algebraic_kernel (algebraic.hip).  Same results as that kernel bit for
+// (Round 3: the Euklid tag and, on the bit-plane chain, erasures are served here too -- algebraic_chunk_supported.)  Same results as that kernel bit for
 // bit (tests/test_gpu_algebraic.py runs both through CC_AMD_NO_CHUNK=1).
 #include <cstdlib>
 #include <type_traits>
@@ -435,6 +435,7 @@ __host__ __device__ inline BmLayout bm_layout(int t2) {
 // what it is sized for.
 __global__ void __launch_bounds__(256, 3)
 chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
+                const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
                 uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
                 uint4 *__restrict__ lamp, uint32_t *__restrict__ nleft,
                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
@@ -471,24 +472,43 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
       SL[j * FPW + f] = lg2[v];
       any |= v;
     }
-    const unsigned long long smask = dbg_stop == 1 ? 0ull : __ballot(any != 0 && f < frames);
+    // erasures of the lane's frame (CSR; none without the arrays): more than 2t cannot be located (bch.h:105-107)
+    uint32_t rho = 0, ebase = 0;
+    if (er_off != nullptr && f < frames) {
+      ebase = er_off[first + f];
+      rho = er_off[first + f + 1] - ebase;
+    }
+    const bool too_many = rho > static_cast<uint32_t>(t2);
+    const unsigned long long smask = dbg_stop == 1 ? 0ull : __ballot(any != 0 && f < frames && !too_many);
     const bool mine = (smask >> lane) & 1ull;
-    if (f < frames && !mine) {  // a codeword: done (cyclic.h:225-231)
-      if (nerr_out) nerr_out[first + f] = 0;
-      if (status_out) status_out[first + f] = CC_FRAME_OK;
+    if (f < frames && !mine) {  // a codeword: done (cyclic.h:225-231) -- or settled as "too many erasures"
+      const bool refused = any != 0 && too_many;
+      if (nerr_out) nerr_out[first + f] = refused ? -1 : 0;
+      if (status_out) status_out[first + f] = refused ? CC_FRAME_ERASURES : CC_FRAME_OK;
     }
     if (lane == 0) mask[chunk] = smask;
     if (smask == 0) continue;  // wave-uniform
 
     // Berlekamp-Massey, one lane per frame (hard_decision.h:116-155)
-    for (int m = 0; m < nc; ++m) {  // lambda = b = 1
-      LL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
-      BL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);
+    for (int m = 0; m < nc; ++m) LL[m * FPW + f] = static_cast<uint16_t>(m == 0 ? 0 : kLogZero);  // lambda = 1
+    // lambda *= (1 + alpha^p x) for every erased position p, :128-131; the recurrence then starts at i = rho with
+    // b = lambda and L = rho
+    const int rmax = static_cast<int>(wave_umax(mine ? rho : 0u));
+    for (int e = 0; e < rmax; ++e) {
+      const bool act = mine && static_cast<uint32_t>(e) < rho;
+      const uint32_t px = act ? static_cast<uint32_t>(er[ebase + e]) % static_cast<uint32_t>(nn) : 0u;
+      for (int m = e + 1; m >= 1; --m) {
+        const uint32_t nv = ex[LL[m * FPW + f]] ^ ex[LL[(m - 1) * FPW + f] + px];
+        if (act) LL[m * FPW + f] = lg2[nv];
+      }
     }
-    int l = 0, shift = 0;  // b is stored unshifted; b(x) x^shift is the polynomial of the recurrence
-    int lw = 0;            // longest register in the wavefront: max(lw, cap) after every step (cap covers all that grew)
+    for (int m = 0; m < nc; ++m) BL[m * FPW + f] = LL[m * FPW + f];
+    const int irho = static_cast<int>(rho);
+    int l = irho, shift = 0;  // b is stored unshifted; b(x) x^shift is the polynomial of the recurrence
+    int lw = rmax;            // longest register in the wavefront: max(lw, cap) after every step (cap covers all that grew)
     for (int i = 0; i < t2; ++i) {
-      shift += 1;  // b = b * x, :134
+      const bool started = i >= irho;  // (a lane with erasures joins at step rho)
+      shift += started ? 1 : 0;        // b = b * x, :134
       uint32_t d = ex[SL[i * FPW + f]];
       const int mm = i < lw ? i : lw;
       // discrepancy :139-141; lambda_m = 0 (log 512) for m > L, and L <= i: running past mm in blocks of U adds zeros
@@ -503,11 +523,11 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
 #pragma unroll
         for (int u = 0; u < U; ++u) d ^= ex[la[u] + sa[u]];
       }
-      const bool upd = mine && d != 0;
-      const bool grow = upd && 2 * l <= i;  // :145 (rho = 0)
+      const bool upd = mine && started && d != 0;
+      const bool grow = upd && 2 * l <= i + irho;  // :145
       const uint32_t ld = lg2[d];
       const uint32_t linv = static_cast<uint32_t>(nn) - ld;  // log of d^-1 (or nn for d = 1: wrapped below)
-      const int lnew = grow ? i + 1 - l : l;
+      const int lnew = grow ? i + irho + 1 - l : l;
       const int cap = static_cast<int>(wave_umax(upd ? static_cast<uint32_t>(lnew) : 0u));
       if (__any(upd)) {
         // lambda += d * b * x^shift, and where the register grows b := lambda_old / d; descending m so that the
@@ -725,8 +745,8 @@ __global__ void __launch_bounds__(256)
 chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
-                 const uint32_t *__restrict__ nleft, uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out,
-                 int32_t *__restrict__ status_out, unsigned long long B) {
+                 const uint32_t *__restrict__ nleft, const uint32_t *__restrict__ er_off, uint8_t *__restrict__ out,
+                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   if (nleft && *nleft == 0) return;  // nothing was handed on by chunk_fixl_kernel (the usual case)
   // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
   // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
@@ -805,8 +825,11 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
         CS[lane] = static_cast<uint8_t>(sv);
         CSL[lane] = lg2[sv];
       }
-      // the PGZ tag runs as bounded-distance decoding: locator degree within capability
-      if (alg != CC_ALG_BM && 2 * deg > t2) status = CC_FRAME_LOCATOR;
+      // the PGZ / Euklid tags run as bounded-distance decoding: locator degree within capability, (2t + rho) / 2
+      const int rho = er_off ? static_cast<int>(er_off[frame + 1] - er_off[frame]) : 0;  // wave-uniform
+      // (erasures reach this chain with the BM tag only: Euklid's integer stop rule, hard_decision.h:176, lets its locator
+      //  be one longer than the capability when rho is odd, and there its answer is not Berlekamp-Massey's)
+      if (alg != CC_ALG_BM && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;
       if (deg < 1) status = CC_FRAME_LOCATOR;  // cyclic.h:145-147
       if (dbg_stop == 2) status = CC_FRAME_LOCATOR;
 
@@ -887,8 +910,9 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
 #pragma unroll
         for (int c = 0; c < 4; ++c) corr[c] = isroot[c];
       }
-      // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip), evaluated otherwise
-      if (status == CC_FRAME_OK && len != deg) {
+      // re-check (cyclic.h:243-248): decided by L = deg lambda (proof in algebraic.hip; with erasures it needs the error
+      // VALUES to be the ones the syndromes determine, which a binary code's all-ones are not), evaluated otherwise
+      if (status == CC_FRAME_OK && (len != deg || (rho > 0 && !is_rs))) {
         uint32_t ly[4], ev[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -941,8 +965,9 @@ __global__ void __launch_bounds__(256)
 chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                   const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                   const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ rootsT,
-                  unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, uint8_t *__restrict__ out,
-                  int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
+                  unsigned long long *__restrict__ left, uint32_t *__restrict__ nleft, const uint32_t *__restrict__ er_off,
+                  uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
+                  unsigned long long B) {
   // exl: alpha^i for i < kZ, zero from kZ on; kZ marks a zero operand (log of 0), kZ + kZ still inside the table
   constexpr uint32_t kZ = 8448, kLongSize = 2 * kZ + 64, kN = 255;
   __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256 + 4 * 32 * 64];
@@ -977,14 +1002,16 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     const bool dirty = (smask >> lane) & 1ull;
     const uint32_t md = dirty ? meta[frame] : 0u;
     const int deg = md & 0xFF, len = md >> 8;
-    const bool general = dirty && (deg > 16 || len != deg);  // chunk_fix_kernel's business
+    const int rho = (er_off && dirty) ? static_cast<int>(er_off[frame + 1] - er_off[frame]) : 0;
+    // chunk_fix_kernel's business: long locators, L != deg lambda, and binary codes with erasures (re-check to be evaluated)
+    const bool general = dirty && (deg > 16 || len != deg || (rho > 0 && !is_rs));
     const unsigned long long lmask = __ballot(general);
     if (lane == 0) {
       left[chunk] = lmask;
       if (lmask) atomicAdd(nleft, 1u);
     }
     int status = CC_FRAME_OK;
-    if (alg != CC_ALG_BM && 2 * deg > t2) status = CC_FRAME_LOCATOR;  // bounded-distance decoding
+    if (alg != CC_ALG_BM && 2 * deg - rho > t2) status = CC_FRAME_LOCATOR;  // bounded-distance decoding (rho = 0 here: see chunk_fix_kernel)
     if (deg < 1) status = CC_FRAME_LOCATOR;                            // cyclic.h:145-147
     const unsigned long long group = 2 * chunk + (f >> 5);
     const int fi = f & 31, bit = 8 * (fi & 3) + (fi >> 2);
@@ -1099,7 +1126,13 @@ bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
     const char *e = std::getenv("CC_AMD_NO_CHUNK");
     return e && e[0] == '1';
   }();
-  if (disabled || erasures) return false;
+  if (disabled) return false;
+  // with erasures: the bit-plane chain only (its LDS-form Berlekamp-Massey kernel starts the recurrence per lane), and the
+  // BM tag only.  Euklid: with an odd number of erasures the remainder sequence stops one step later than the capability
+  // (integer (2t + rho) / 2, hard_decision.h:176) and the reference decodes frames with 2e + rho = 2t + 1 -- to ITS
+  // answer, which is not Berlekamp-Massey's (measured: RS(255,223), rho = 31, one error); Sugiyama itself runs in
+  // algebraic.hip.  PGZ: two trials without erasures for BCH, refused for RS.
+  if (erasures) return bitslice_supported(code) && code->desc.algorithm == CC_ALG_BM;
   // measured (profiles/tools/rs_bench.py): with few syndromes the per-frame work is dominated by the frame's
   // load/store latency and the one-wavefront-per-frame kernel with its higher occupancy wins
   // (BCH(255,231), 6 syndromes: 1128 vs 899 M frames/s); with 32 syndromes this kernel wins (309 vs 220)
@@ -1176,8 +1209,9 @@ static int launch_chunk_fpw(const cc_code *code, bool float_in, const void *d_in
 }
 
 // syndromes on bit planes (bitslice.hip), Berlekamp-Massey over chunks of 64 frames, root search on planes, corrections
-static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
-                                  int32_t *d_status, size_t B, hipStream_t stream) {
+static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                                  const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                                  hipStream_t stream) {
   const int t2 = static_cast<int>(code->tab.roots.size()), nc = t2 + 1;
   const unsigned long long G = (B + 31) / 32, chunks = (B + 63) / 64;
   const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;  // syndromes, locators and root masks are laid out in blocks of 64 groups
@@ -1214,15 +1248,15 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
     if (e == hipSuccess) {
       const unsigned long long reg_cap = static_cast<unsigned long long>(code->num_cus) * 3;
       const int reg_grid = static_cast<int>(blocks_needed < reg_cap ? blocks_needed : reg_cap);
-      if (t2 == 32)
+      if (t2 == 32 && !d_er_off)  // (with erasures the recurrence starts per lane at i = rho: the LDS form below)
         hipLaunchKernelGGL((chunk_bm_reg_kernel<32>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
                            d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
-      else if (t2 == 16)
+      else if (t2 == 16 && !d_er_off)
         hipLaunchKernelGGL((chunk_bm_reg_kernel<16>), dim3(reg_grid), dim3(256), 0, stream, code->d_alg, dbg_stop, d_synd,
                            d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       else
-        hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_llg, d_meta,
-                           d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
+        hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_er, d_er_off,
+                           d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       e = hipGetLastError();
     }
     if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, stream) != CC_OK) e = hipErrorLaunchFailure;
@@ -1241,7 +1275,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
           const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * fixl_per_cu;
           const int lgrid = static_cast<int>(blocks_needed < lcap ? blocks_needed : lcap);
           hipLaunchKernelGGL(chunk_fixl_kernel, dim3(lgrid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm | fixl_exp(), d_synd,
-                             d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_out,
+                             d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_er_off, d_out,
                              d_nerr, d_status, Bq);
           e = hipGetLastError();
         }
@@ -1249,7 +1283,7 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
       if (e == hipSuccess) {
         hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
                            code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, four ? d_left : d_mask,
-                           reinterpret_cast<const uint32_t *>(d_roots), four ? d_nleft : nullptr, d_out, d_nerr, d_status,
+                           reinterpret_cast<const uint32_t *>(d_roots), four ? d_nleft : nullptr, d_er_off, d_out, d_nerr, d_status,
                            Bq);
         e = hipGetLastError();
       }
@@ -1260,10 +1294,12 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   return rc;
 }
 
-int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
-                           int32_t *d_status, size_t B, hipStream_t stream) {
+int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                           const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                           hipStream_t stream) {
   if (B == 0) return CC_OK;
-  if (bitslice_supported(code)) return launch_chunk_bitsliced(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
+  if (bitslice_supported(code))
+    return launch_chunk_bitsliced(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
   return launch_chunk_fpw<32>(code, float_in, d_in, d_out, d_nerr, d_status, B, stream);
 }
 

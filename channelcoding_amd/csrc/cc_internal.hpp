@@ -172,8 +172,9 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
                      hipStream_t stream);
 // algebraic_chunk.hip: BM / PGZ without erasures, Berlekamp-Massey with one lane per frame
 bool algebraic_chunk_supported(const cc_code *code, bool erasures);
-int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, int32_t *d_nerr,
-                           int32_t *d_status, size_t B, hipStream_t stream);
+int launch_algebraic_chunk(const cc_code *code, bool float_in, const void *d_in, const uint16_t *d_er,
+                           const uint32_t *d_er_off, uint8_t *d_out, int32_t *d_nerr, int32_t *d_status, size_t B,
+                           hipStream_t stream);
 // bitslice.hip: syndromes of GF(2^8) codes on bit planes (32 frames per register)
 bool bitslice_supported(const cc_code *code);
 int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_in, uint8_t *d_out, uint8_t *d_synd, size_t B,

@@ -5,7 +5,7 @@ boundary (32 frames per group, 64 per chunk, 2048 per block)."""
 import numpy as np
 import pytest
 
-from checkers import BCH, BM, PGZ, RS, Oracle
+from checkers import BCH, BM, EUKLID, PGZ, RS, Oracle
 from test_gpu_algebraic import TAGS, check_against_oracle, corrupt
 
 import channelcoding_amd as cc
@@ -145,3 +145,44 @@ def test_small_calls_at_default_settings():
     env = {k: v for k, v in os.environ.items() if k != "CC_AMD_PLANES_MIN_WORK"}
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DEFAULT OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("fam,t,alg", [(RS, 16, BM), (RS, 8, BM), (RS, 5, BM), (BCH, 4, BM), (BCH, 9, BM), (RS, 2, BM)])
+def test_erasures_on_the_plane_chain(fam, t, alg):
+    """Erasure decoding on the bit-plane chain (round 3: chunk_bm_kernel pre-loads the erasure locator per lane and
+    starts the recurrence at i = rho; locators up to degree 16 are corrected lane-per-frame, longer ones and binary
+    codes go through chunk_fix_kernel; BM tag -- the Euklid tag keeps Sugiyama's own kernel with erasures): 0 .. 2t erasures per frame (beyond 2t: CC_FRAME_ERASURES, checked at the end), errors up to
+    and beyond the capability, clean frames with erasures, ragged batch sizes; against the oracle frame by frame."""
+    from test_gpu_algebraic import check_erasure_frames
+    o = Oracle(fam, 8, t)
+    code = make(fam, t, alg)
+    assert code.kernel_info()["kernel"].startswith("algebraic_chunk_kernel")
+    rng = np.random.default_rng(31 * t + alg)
+    hi = 2 if fam == BCH else 256
+    for frames in (1, 65, 333):
+        cw = o.encode(rng.integers(0, hi, (frames, o.l)).astype(np.uint8))
+        rx = cw.copy()
+        ers = []
+        for f in range(frames):
+            ne = int(rng.integers(0, 2 * o.t + 1))
+            er = sorted(rng.choice(o.n, ne, replace=False).tolist())
+            for e in er:
+                rx[f, e] = int(rng.integers(0, hi))  # (an erased symbol may be right by chance)
+            free = np.setdiff1d(np.arange(o.n), er)
+            room = max(0, (2 * o.t - ne) // 2)
+            for p in rng.choice(free, int(rng.integers(0, room + 2)), replace=False):
+                rx[f, p] ^= 1 if fam == BCH else int(rng.integers(1, hi))
+            ers.append(er)
+        ers[0] = []  # a frame without erasures among them
+        if frames > 1:
+            rx[1] = cw[1]  # a clean frame that carries erasures
+        check_erasure_frames(code, o, alg, rx, ers)
+    # more than 2t erasures: CC_FRAME_ERASURES and the word untouched (the device's own class for it, as on the
+    # one-wavefront-per-frame kernel; the reference's BM path fails later with another text) -- unless the word is clean
+    cw = o.encode(rng.integers(0, hi, (40, o.l)).astype(np.uint8))
+    rx = cw.copy()
+    rx[::2, 7] ^= 1
+    ers = [sorted(rng.choice(o.n, 2 * o.t + 1 + (f % 3), replace=False).tolist()) for f in range(40)]
+    res = code.correct_batch(rx, erasures=ers)
+    assert (res["status"][::2] == 4).all() and (res["nerr"][::2] == -1).all() and np.array_equal(res["out"], rx)
+    assert (res["status"][1::2] == 0).all() and (res["nerr"][1::2] == 0).all()
