@@ -1271,7 +1271,7 @@ int cc_kernel_info(const cc_code *code, char *name, size_t cap, uint32_t *frames
     minsum_kernel_info(code, nm, f, t, l);
   } else if (algebraic_chunk_supported(code, false)) {
     if (bitslice_supported(code)) {
-      nm = "algebraic_chunk_kernel on bit planes: bitslice_fused_syndrome / chunk_bm_reg / bitslice_chien / chunk_fixl kernels (algebraic_kernel with erasures)";
+      nm = "algebraic_chunk_kernel on bit planes: bitslice_fused_syndrome / chunk_bm_reg / bitslice_chien / chunk_fixl kernels (erasures: chunk_bm with the BM tag, algebraic_kernel with Euklid; small calls: algebraic_kernel)";
       f = 256;
     } else {
       nm = "algebraic_chunk_kernel<FPW=32> (algebraic_kernel with erasures)";
