@@ -139,6 +139,7 @@ def secondary_workloads(torch, cc, capi, dev):
     headline_point("bch255_231_ms20_4dB_stop_rule_O0_as_shipped_2^20", 4.0, stop_rule=0)
     headline_point("bch255_231_nms20_0.8_4dB_2^20", 4.0, tag=cc.normalized_min_sum_tag(20, 0.8))
     headline_point("bch255_231_scms1_20_4dB_2^20", 4.0, tag=cc.self_correcting_1_min_sum_tag(20))
+    headline_point("bch255_231_scms2_20_4dB_2^20", 4.0, tag=cc.self_correcting_2_min_sum_tag(20))
     del y, hard
     # configs[3]
     rs = cc.rs(8, cc.errors(16), cc.berlekamp_massey_tag())
@@ -166,6 +167,20 @@ def secondary_workloads(torch, cc, capi, dev):
                                     "all_frames_corrected": bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0}
     enc_ms = timed(lambda: rs.encode_batch(cw[:, rs.k:].contiguous()))
     out["rs255_223_encode_2^20"] = {"frames_per_s": B / (enc_ms * 1e-3), "kernel_ms": enc_ms}
+    # errors and erasures (BM tag): 4 erased positions (zeroed, passed as CSR) + 0 .. 6 errors elsewhere per frame
+    rho, maxe = 4, 6
+    pos = torch.rand((B, rs.n), device=dev, generator=g).argsort(dim=1)[:, :rho + maxe]
+    nerr = torch.randint(0, maxe + 1, (B,), device=dev, generator=g)
+    vals = torch.randint(1, 256, (B, maxe), dtype=torch.uint8, device=dev, generator=g)
+    vals = torch.where(torch.arange(maxe, device=dev)[None, :] < nerr[:, None], vals, torch.zeros_like(vals))
+    rxe = cw.clone()
+    rxe.scatter_(1, pos[:, rho:], rxe.gather(1, pos[:, rho:]) ^ vals)
+    rxe.scatter_(1, pos[:, :rho], torch.zeros((B, rho), dtype=torch.uint8, device=dev))
+    er = pos[:, :rho].sort(dim=1).values.to(torch.int16).contiguous().view(-1)
+    off = (torch.arange(B + 1, device=dev, dtype=torch.int64) * rho).to(torch.int32)
+    ms_x = timed(lambda: lib.cc_correct_hard_batch_dev(rs._h, vp(rxe), vp(er), vp(off), vp(outw), vp(ne), vp(st), B, sh))
+    out["rs255_223_bm_4_erasures_2^20"] = {"frames_per_s": B / (ms_x * 1e-3), "kernel_ms": ms_x,
+                                           "all_frames_corrected": bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0}
     return out
 
 
