@@ -67,7 +67,8 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   WaveScratch &W = scratch[wid];
-  const int dbg_stop = alg >> 8;  // timing experiments only (CC_AMD_ALG_STOP): 1 after syndromes, 2 after BM, 3 after roots
+  const int dbg_stop = (alg >> 8) & 0xFF;  // timing experiments only (CC_AMD_ALG_STOP): 1 after syndromes, 2 after BM, 3 after roots
+  const bool redo = (alg >> 16) & 1;       // only the frames another path left with a non-zero status (launch_algebraic)
   alg &= 0xFF;
   const int n = T->n, nroots = T->nroots, nn = n;  // full-length codes: n = 2^q - 1
   const int t2 = nroots;
@@ -94,6 +95,7 @@ algebraic_kernel(const AlgebraicTables *__restrict__ T, int alg, const void *__r
   }
 
   for (unsigned long long frame = wave; frame < B; frame += nwaves) {
+    if (redo && status_out[frame] == CC_FRAME_OK) continue;  // wave-uniform
     // ---- load (hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52) ----
     uint32_t sym[4];
 #pragma unroll
@@ -430,6 +432,26 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
   const bool small_call = bitslice_supported(code) && B * code->tab.roots.size() < planes_min_work;
   if (algebraic_chunk_supported(code, d_er_off != nullptr) && !small_call)
     return launch_algebraic_chunk(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
+  // The Euklid tag WITH erasures on a bit-plane code: the chain first, as bounded-distance Berlekamp-Massey -- a frame
+  // it corrects lies within the capability (2e + rho <= 2t), where the key equation has one solution and Sugiyama's
+  // remainder sequence finds the same one -- then Sugiyama itself (the kernel below, in place on the output) over the
+  // frames the chain left with a non-zero status: the hopeless ones, and the ones hard_decision.h:176's integer stop
+  // rule lets the reference decode beyond the capability when rho is odd (E39).
+  const bool chain_first = d_er_off != nullptr && code->desc.algorithm == CC_ALG_EUKLID && bitslice_supported(code) && !small_call;
+  int32_t *st_tmp = nullptr;
+  if (chain_first) {
+    if (d_status == nullptr) {
+      CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&st_tmp), B * sizeof(int32_t), stream));
+      d_status = st_tmp;
+    }
+    const int rc = launch_algebraic_chunk(code, float_in, d_in, d_er, d_er_off, d_out, d_nerr, d_status, B, stream);
+    if (rc != CC_OK) {
+      if (st_tmp) (void)hipFreeAsync(st_tmp, stream);
+      return rc;
+    }
+    d_in = d_out;  // (failed frames hold the received word, hard-decided)
+    float_in = false;
+  }
   const unsigned long long blocks_needed = (B + 3) / 4;
   const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 16;
   const int grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
@@ -447,7 +469,7 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
   // hard_decision.h:157-196 (argument in algebraic_chunk_supported, algebraic_chunk.hip); Sugiyama itself runs where
   // the erasure locator enters the start polynomials.
   const int alg_eff = (code->desc.algorithm == CC_ALG_EUKLID && d_er_off == nullptr) ? CC_ALG_PGZ : code->desc.algorithm;
-  const int alg_arg = alg_eff | (dbg_stop << 8);
+  const int alg_arg = alg_eff | (dbg_stop << 8) | (chain_first ? 1 << 16 : 0);
   if (float_in)
     hipLaunchKernelGGL(algebraic_kernel<true>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg, d_in,
                        d_er, d_er_off, d_out, d_nerr, d_status, Bq);
@@ -455,6 +477,7 @@ int launch_algebraic(const cc_code *code, bool float_in, const void *d_in, const
     hipLaunchKernelGGL(algebraic_kernel<false>, dim3(grid), dim3(256), 0, stream, code->d_alg, alg_arg,
                        d_in, d_er, d_er_off, d_out, d_nerr, d_status, Bq);
   hipError_t e = hipGetLastError();
+  if (st_tmp) (void)hipFreeAsync(st_tmp, stream);
   if (e != hipSuccess) return hip_fail(e, "algebraic kernel launch");
   return CC_OK;
 }

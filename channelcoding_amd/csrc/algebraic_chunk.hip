@@ -1130,8 +1130,9 @@ bool algebraic_chunk_supported(const cc_code *code, bool erasures) {
   // with erasures: the bit-plane chain only (its LDS-form Berlekamp-Massey kernel starts the recurrence per lane), and the
   // BM tag only.  Euklid: with an odd number of erasures the remainder sequence stops one step later than the capability
   // (integer (2t + rho) / 2, hard_decision.h:176) and the reference decodes frames with 2e + rho = 2t + 1 -- to ITS
-  // answer, which is not Berlekamp-Massey's (measured: RS(255,223), rho = 31, one error); Sugiyama itself runs in
-  // algebraic.hip.  PGZ: two trials without erasures for BCH, refused for RS.
+  // answer, which is not Berlekamp-Massey's (measured: RS(255,223), rho = 31, one error); launch_algebraic runs this
+  // chain FIRST for the Euklid tag too and Sugiyama itself over the frames it leaves undecoded.  PGZ: two trials without
+  // erasures for BCH, refused for RS.
   if (erasures) return bitslice_supported(code) && code->desc.algorithm == CC_ALG_BM;
   // measured (profiles/tools/rs_bench.py): with few syndromes the per-frame work is dominated by the frame's
   // load/store latency and the one-wavefront-per-frame kernel with its higher occupancy wins

@@ -147,11 +147,13 @@ def test_small_calls_at_default_settings():
     assert out.returncode == 0 and "DEFAULT OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("fam,t,alg", [(RS, 16, BM), (RS, 8, BM), (RS, 5, BM), (BCH, 4, BM), (BCH, 9, BM), (RS, 2, BM)])
+@pytest.mark.parametrize("fam,t,alg", [(RS, 16, BM), (RS, 16, EUKLID), (RS, 8, BM), (RS, 5, EUKLID), (BCH, 4, BM), (BCH, 9, EUKLID),
+                                       (RS, 2, BM)])
 def test_erasures_on_the_plane_chain(fam, t, alg):
     """Erasure decoding on the bit-plane chain (round 3: chunk_bm_kernel pre-loads the erasure locator per lane and
     starts the recurrence at i = rho; locators up to degree 16 are corrected lane-per-frame, longer ones and binary
-    codes go through chunk_fix_kernel; BM tag -- the Euklid tag keeps Sugiyama's own kernel with erasures): 0 .. 2t erasures per frame (beyond 2t: CC_FRAME_ERASURES, checked at the end), errors up to
+    codes go through chunk_fix_kernel; the Euklid tag runs the same chain as bounded-distance BM and then Sugiyama's own
+    kernel over the frames it left undecoded -- the reference decodes some of those when rho is odd): 0 .. 2t erasures per frame (beyond 2t: CC_FRAME_ERASURES, checked at the end), errors up to
     and beyond the capability, clean frames with erasures, ragged batch sizes; against the oracle frame by frame."""
     from test_gpu_algebraic import check_erasure_frames
     o = Oracle(fam, 8, t)
