@@ -188,3 +188,25 @@ def test_erasures_on_the_plane_chain(fam, t, alg):
     res = code.correct_batch(rx, erasures=ers)
     assert (res["status"][::2] == 4).all() and (res["nerr"][::2] == -1).all() and np.array_equal(res["out"], rx)
     assert (res["status"][1::2] == 0).all() and (res["nerr"][1::2] == 0).all()
+
+
+def test_erasure_paths_agree():
+    """profiles/tools/erasure_soak.py: 2^14 seeded frames x 8 configurations (RS / BCH, BM / Euklid tag; 0 .. 2t + 2
+    erasures, errors up to and beyond the capability, clean frames with erasures) through the bit-plane chain and through
+    the one-wavefront-per-frame kernel, in a process each (the switch is read once): the same words, counts and status
+    of every frame (SHA-256 of the three arrays) -- all four failure classes occur."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "profiles", "tools", "erasure_soak.py")
+    outs = []
+    for work in ("0", "1000000000000"):
+        r = subprocess.run([sys.executable, tool, "14"], env=dict(os.environ, CC_AMD_PLANES_MIN_WORK=work),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if "digest" in l]
+        assert len(lines) == 8 and all(" rc 0 " in l for l in lines), r.stdout[-2000:]
+        outs.append(lines)
+    assert outs[0] == outs[1], "\n".join(a + "\n" + b for a, b in zip(*outs) if a != b)
+    assert any("erasures 0 " not in l for l in outs[0]) and any("recheck 0 " not in l for l in outs[0])
