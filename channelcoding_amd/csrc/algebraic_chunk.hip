@@ -23,7 +23,7 @@
 #include "wave_ops.hpp"
 
 namespace ccamd {
-int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream);  // bitslice.hip
+int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, bool long_locators, hipStream_t stream);  // bitslice.hip
 int launch_bitslice_roots_transpose(const void *d_masks, void *d_rootsT, size_t B, hipStream_t stream);
 namespace {
 
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256, 3)
 chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8_t *__restrict__ synd,
                 const uint16_t *__restrict__ er, const uint32_t *__restrict__ er_off,
                 uint16_t *__restrict__ llg, uint16_t *__restrict__ meta, unsigned long long *__restrict__ mask,
-                uint4 *__restrict__ lamp, uint32_t *__restrict__ nleft,
+                uint4 *__restrict__ lamp, int ncoef, uint32_t *__restrict__ nleft,
                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (blockIdx.x == 0 && threadIdx.x == 0) *nleft = 0;  // chunks chunk_fixl_kernel will hand on (it runs after this kernel)
@@ -575,8 +575,9 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
     // dwords (word j = frames 4j .. 4j+3) through the butterfly, so bit 8 (f & 3) + (f >> 2) of a plane belongs to
     // frame f of the group
     uint8_t *LV = reinterpret_cast<uint8_t *>(BL);
-    for (int m = 0; m < 17 && m < nc; ++m) LV[m * FPW + f] = ex[LL[m * FPW + f]];
-    if (lane < 2 * 17) {
+    // (ncoef = 17 coefficients for the root search on planes, 25 for calls with erasures: bitslice.hip)
+    for (int m = 0; m < ncoef && m < nc; ++m) LV[m * FPW + f] = ex[LL[m * FPW + f]];
+    if (lane < 2 * ncoef) {
       const int m = lane >> 1, half = lane & 1;
       uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (m < nc) {
@@ -586,7 +587,7 @@ chunk_bm_kernel(const AlgebraicTables *__restrict__ T, int dbg_stop, const uint8
         bitplane::butterfly(w);
       }
       const unsigned long long g = 2 * chunk + half;
-      uint4 *dst = lamp + (((g >> 6) * 17 + m) * 64 + (g & 63)) * 2;
+      uint4 *dst = lamp + (((g >> 6) * ncoef + m) * 64 + (g & 63)) * 2;
       dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
@@ -745,8 +746,9 @@ __global__ void __launch_bounds__(256)
 chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                  const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
                  const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ roots,
-                 const uint32_t *__restrict__ nleft, const uint32_t *__restrict__ er_off, uint8_t *__restrict__ out,
-                 int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out, unsigned long long B) {
+                 const uint32_t *__restrict__ nleft, const uint32_t *__restrict__ er_off, int plane_deg,
+                 uint8_t *__restrict__ out, int32_t *__restrict__ nerr_out, int32_t *__restrict__ status_out,
+                 unsigned long long B) {
   if (nleft && *nleft == 0) return;  // nothing was handed on by chunk_fixl_kernel (the usual case)
   // exl: antilog table long enough for a Horner / Chien exponent that is never wrapped -- index = log of the
   // coefficient (<= 254, or kLongZero for a zero coefficient) + up to 32 steps of <= 254; zero above kLongZero
@@ -837,7 +839,7 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
       uint32_t isroot[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
       if (status == CC_FRAME_OK) {
         uint32_t acc[4] = {0, 0, 0, 0};
-        if (deg <= 16) {  // searched on planes already
+        if (deg <= plane_deg) {  // searched on planes already (16, or 24 for calls with erasures)
           const int fi = s & 31, bit = 8 * (fi & 3) + (fi >> 2);
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] = (((s >> 5) ? rw[1][c] : rw[0][c]) >> bit) & 1u ? 0u : 1u;
@@ -961,6 +963,8 @@ chunk_fix_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *
 // coefficient indices and unwrapped exponents on the long antilog table.  No cross-lane traffic at all; a trip of
 // the error loop serves up to 64 frames.  Frames that need the general treatment -- locator longer than 16, or L != deg (the re-check has to be
 // evaluated) -- go to chunk_fix_kernel through `left`.
+// MD = longest locator served here: 16 (= t of the largest code; calls without erasures), 24 for calls with erasures
+template <int MD>
 __global__ void __launch_bounds__(256)
 chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t *__restrict__ synd,
                   const uint16_t *__restrict__ llg, const uint16_t *__restrict__ meta,
@@ -970,11 +974,11 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
                   unsigned long long B) {
   // exl: alpha^i for i < kZ, zero from kZ on; kZ marks a zero operand (log of 0), kZ + kZ still inside the table
   constexpr uint32_t kZ = 8448, kLongSize = 2 * kZ + 64, kN = 255;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256 + 4 * 32 * 64];
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kLongSize + 512 + 256 + 4 * 2 * MD * 64];
   uint8_t *exl = smem;
   uint16_t *lgz = reinterpret_cast<uint16_t *>(smem + kLongSize);  // [256] log, kZ for 0
   uint8_t *lg = smem + kLongSize + 512;                            // [256] plain log table (log 0 = 0)
-  uint8_t *plist = smem + kLongSize + 512 + 256;                   // [wavefront][32][64] error positions, symbols
+  uint8_t *plist = smem + kLongSize + 512 + 256;                   // [wavefront][2 MD][64] error positions, symbols
   for (uint32_t i = threadIdx.x; i < kLongSize; i += 256) exl[i] = i < kZ ? T->exp[i % 255u] : 0;
   lgz[threadIdx.x] = static_cast<uint16_t>(threadIdx.x ? T->log[threadIdx.x] : kZ);
   lg[threadIdx.x] = T->log[threadIdx.x];
@@ -1004,7 +1008,7 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     const int deg = md & 0xFF, len = md >> 8;
     const int rho = (er_off && dirty) ? static_cast<int>(er_off[frame + 1] - er_off[frame]) : 0;
     // chunk_fix_kernel's business: long locators, L != deg lambda, and binary codes with erasures (re-check to be evaluated)
-    const bool general = dirty && (deg > 16 || len != deg || (rho > 0 && !is_rs));
+    const bool general = dirty && (deg > MD || len != deg || (rho > 0 && !is_rs));
     const unsigned long long lmask = __ballot(general);
     if (lane == 0) {
       left[chunk] = lmask;
@@ -1034,7 +1038,7 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     // the error positions of every lane as a list in LDS ([error][lane], bytes): taking them off the root words inside
     // the Forney loop would cost a trip per (word, error-in-word) of the WORST lane -- about 36 trips for 8 errors
     // per frame -- instead of one per error of the worst lane
-    uint8_t *PL = plist + wid * (32 * 64);  // [16][64] positions, [16][64] symbols
+    uint8_t *PL = plist + wid * (2 * MD * 64);  // [MD][64] positions, [MD][64] symbols
     uint32_t have = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1047,14 +1051,14 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         w &= w - 1;
       }
     }
-    const int emax = (xf & 4) ? 0 : static_cast<int>(wave_umax(have));  // <= 16: a fixing lane has cnt = deg <= 16 roots
+    const int emax = (xf & 4) ? 0 : static_cast<int>(wave_umax(have));  // <= MD: a fixing lane has cnt = deg <= MD roots
     // All symbols to patch are requested here (four at a time, into LDS), long before the first one is stored: the
     // memory counter retires in order, so a load issued after a store would wait for that store's acknowledgement on
     // every trip (measured: 272 us for the kernel with load and store alternating, 150 / 165 us with only one of them).
     const uint8_t *obase = out + first * n;  // wave-uniform base + 32-bit lane offset
-    uint32_t ll[17], ol[16], sl[16];  // log lambda_m, log omega_j, log S_j (kZ for zero); j < 16: omega_j, j < deg <= 16, needs no more
+    uint32_t ll[MD + 1], ol[MD], sl[MD];  // log lambda_m, log omega_j, log S_j (kZ for zero); j < MD: omega_j, j < deg <= MD, needs no more
     {
-      for (int e0 = 0; e0 < 16; e0 += 4) {
+      for (int e0 = 0; e0 < MD; e0 += 4) {
         uint32_t sy[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1062,25 +1066,25 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
           sy[u] = has ? obase[static_cast<uint32_t>(f * n) + PL[(e0 + u) * 64 + lane]] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) PL[(16 + e0 + u) * 64 + lane] = static_cast<uint8_t>(sy[u]);
+        for (int u = 0; u < 4; ++u) PL[(MD + e0 + u) * 64 + lane] = static_cast<uint8_t>(sy[u]);
       }
       if (is_rs) {
         const uint8_t *sb = synd + ((group >> 6) * t2 * 64 + (group & 63)) * 32 + 4 * (fi & 7) + (fi >> 3);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sl[j] = j < t2 ? sb[j * 2048] : 0u;
+        for (int j = 0; j < MD; ++j) sl[j] = j < t2 ? sb[j * 2048] : 0u;
 #pragma unroll
-        for (int m = 0; m < 17; ++m) ll[m] = m < nc ? llg[(chunk * nc + m) * 64 + f] : kLogZero;
+        for (int m = 0; m < MD + 1; ++m) ll[m] = m < nc ? llg[(chunk * nc + m) * 64 + f] : kLogZero;
       }
     }
     if (is_rs) {
 #pragma unroll
-      for (int m = 0; m < 17; ++m) ll[m] = ll[m] >= kLogZero ? kZ : ll[m];
+      for (int m = 0; m < MD + 1; ++m) ll[m] = ll[m] >= kLogZero ? kZ : ll[m];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) sl[j] = lgz[sl[j]];
+      for (int j = 0; j < MD; ++j) sl[j] = lgz[sl[j]];
       const uint32_t dmax = static_cast<uint32_t>(wave_umax(fixing ? static_cast<uint32_t>(deg) : 0u));
       // omega_j = sum_{m <= j} lambda_m S_{j-m} for j < deg (S lambda mod x^deg)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < MD; ++j) {
         uint32_t om = 0;
         if (static_cast<uint32_t>(j) < dmax && !(xf & 8)) {  // wave-uniform
 #pragma unroll
@@ -1092,7 +1096,7 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
     for (int e = 0; e < emax; ++e) {
       const bool has = static_cast<uint32_t>(e) < have;
       const uint32_t p = has ? PL[e * 64 + lane] : 0u;
-      const uint32_t sym = PL[(16 + e) * 64 + lane];
+      const uint32_t sym = PL[(MD + e) * 64 + lane];
       uint32_t y = 1;  // bch.h:80-83
       if (is_rs && !(xf & 2)) {  // Forney, rs.h:41-78
         const uint32_t xi = p ? kN - p : 0u;  // log X^-1
@@ -1100,13 +1104,13 @@ chunk_fixl_kernel(const AlgebraicTables *__restrict__ T, int alg, const uint8_t 
         x2 = umin32(x2, x2 - kN);
         uint32_t num = 0, den = 0, ee = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {  // omega(X^-1)
+        for (int j = 0; j < MD; ++j) {  // omega(X^-1)
           num ^= exl[ol[j] + ee];
           ee += xi;
         }
         ee = 0;
 #pragma unroll
-        for (int m = 1; m < 17; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
+        for (int m = 1; m < MD + 1; m += 2) {  // lambda'(X^-1) = sum_{m odd} lambda_m X^-(m-1)
           den ^= exl[ll[m] + ee];
           ee += x2;
         }
@@ -1220,7 +1224,12 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
   const size_t synd_bytes = G64 * t2 * 32;
   const size_t llg_bytes = up(static_cast<size_t>(chunks) * nc * 64 * 2), meta_bytes = up(static_cast<size_t>(chunks) * 64 * 2);
   const size_t mask_bytes = up(static_cast<size_t>(chunks) * 8);
-  const size_t lamp_bytes = G64 * 17 * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
+  // calls with erasures: combined (erasure x error) locators up to degree 24 on the lane-per-frame path -- 25 coefficient
+  // planes, the long instantiations of the root search and of the corrector; without erasures a correctable locator
+  // has degree <= t <= 16
+  const bool long_loc = d_er_off != nullptr && t2 > 16;
+  const int ncoef = long_loc ? 25 : 17;
+  const size_t lamp_bytes = G64 * ncoef * 32, roots_bytes = G64 * 256 * 4, left_bytes = mask_bytes;
   uint8_t *ws = nullptr;  // stream-ordered and pool-cached: no device-wide synchronisation, no allocation after the first call
   CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws),
                             synd_bytes + llg_bytes + meta_bytes + mask_bytes + lamp_bytes + 2 * roots_bytes + left_bytes + 256, stream));
@@ -1257,10 +1266,10 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
                            d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
       else
         hipLaunchKernelGGL(chunk_bm_kernel, dim3(grid), dim3(256), lds, stream, code->d_alg, dbg_stop, d_synd, d_er, d_er_off,
-                           d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), d_nleft, d_nerr, d_status, Bq);
+                           d_llg, d_meta, d_mask, reinterpret_cast<uint4 *>(d_lamp), ncoef, d_nleft, d_nerr, d_status, Bq);
       e = hipGetLastError();
     }
-    if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, stream) != CC_OK) e = hipErrorLaunchFailure;
+    if (e == hipSuccess && launch_bitslice_chien(d_lamp, d_roots, B, long_loc, stream) != CC_OK) e = hipErrorLaunchFailure;
     if (e == hipSuccess) {
       max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
       grid = static_cast<int>(blocks_needed < max_grid ? blocks_needed : max_grid);
@@ -1268,24 +1277,34 @@ static int launch_chunk_bitsliced(const cc_code *code, bool float_in, const void
       if (four) {  // one lane per frame; what it cannot settle goes on through d_left
         if (launch_bitslice_roots_transpose(d_roots, d_rootsT, B, stream) != CC_OK) e = hipErrorLaunchFailure;
         if (e == hipSuccess) {
-          static const int fixl_per_cu = [] {  // resident workgroups per CU: registers and LDS of the built kernel
-            int v = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, chunk_fixl_kernel, 256, 0) != hipSuccess || v < 1) v = 3;
-            return v;
-          }();
-          const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * fixl_per_cu;
+          static const int fixl_per_cu[2] = {[] {  // resident workgroups per CU: registers and LDS of the built kernels
+                                               int v = 0;
+                                               if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, chunk_fixl_kernel<16>, 256, 0) != hipSuccess || v < 1) v = 3;
+                                               return v;
+                                             }(),
+                                             [] {
+                                               int v = 0;
+                                               if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, chunk_fixl_kernel<24>, 256, 0) != hipSuccess || v < 1) v = 2;
+                                               return v;
+                                             }()};
+          const unsigned long long lcap = static_cast<unsigned long long>(code->num_cus) * fixl_per_cu[long_loc];
           const int lgrid = static_cast<int>(blocks_needed < lcap ? blocks_needed : lcap);
-          hipLaunchKernelGGL(chunk_fixl_kernel, dim3(lgrid), dim3(256), 0, stream, code->d_alg, code->desc.algorithm | fixl_exp(), d_synd,
-                             d_llg, d_meta, d_mask, reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_er_off, d_out,
-                             d_nerr, d_status, Bq);
+          if (long_loc)
+            hipLaunchKernelGGL(chunk_fixl_kernel<24>, dim3(lgrid), dim3(256), 0, stream, code->d_alg,
+                               code->desc.algorithm | fixl_exp(), d_synd, d_llg, d_meta, d_mask,
+                               reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_er_off, d_out, d_nerr, d_status, Bq);
+          else
+            hipLaunchKernelGGL(chunk_fixl_kernel<16>, dim3(lgrid), dim3(256), 0, stream, code->d_alg,
+                               code->desc.algorithm | fixl_exp(), d_synd, d_llg, d_meta, d_mask,
+                               reinterpret_cast<const uint32_t *>(d_rootsT), d_left, d_nleft, d_er_off, d_out, d_nerr, d_status, Bq);
           e = hipGetLastError();
         }
       }
       if (e == hipSuccess) {
         hipLaunchKernelGGL(chunk_fix_kernel, dim3(grid), dim3(256), 0, stream, code->d_alg,
                            code->desc.algorithm | (dbg_stop << 8), d_synd, d_llg, d_meta, four ? d_left : d_mask,
-                           reinterpret_cast<const uint32_t *>(d_roots), four ? d_nleft : nullptr, d_er_off, d_out, d_nerr, d_status,
-                           Bq);
+                           reinterpret_cast<const uint32_t *>(d_roots), four ? d_nleft : nullptr, d_er_off, long_loc ? 24 : 16,
+                           d_out, d_nerr, d_status, Bq);
         e = hipGetLastError();
       }
     }

@@ -486,16 +486,17 @@ bitslice_parity_kernel(const uint4 *__restrict__ evals, uint8_t *__restrict__ cw
 // i = 8 (f & 3) + (f >> 2) (the order chunk_bm_kernel transposes in).  Coefficients 0 .. 16; frames whose locator is
 // longer are searched by chunk_fix_kernel itself.  Wavefront = 64 groups x 32 positions (segment SEG starts at
 // p = 32 SEG with T_m advanced by alpha^(-32 m SEG)), so a lane writes one 128-byte line of masks[group][256].
-constexpr int kChienCoef = 17;
+constexpr int kChienCoef = 17;      // locators of degree <= 16 = t of the largest code: calls without erasures
+constexpr int kChienCoefLong = 25;  // calls with erasures: combined locators up to degree 24 (algebraic_chunk.hip)
 // rows of the 8 x 8 binary matrices of "times alpha^(-32 m seg)", m = 1 .. 16, seg = 0 .. 7: the advance of T_m to the
 // first position of a segment is the one multiplication whose constant differs from wavefront to wavefront, so it
 // runs as a masked sum (plane c enters plane b under a wave-uniform mask) instead of a hard-wired network
 struct ChienAdvance {
-  uint8_t row[8][kChienCoef - 1][8];
+  uint8_t row[8][kChienCoefLong - 1][8];
   constexpr ChienAdvance() : row{} {
     Gf256 f;
     for (int seg = 0; seg < 8; ++seg)
-      for (int m = 1; m < kChienCoef; ++m) {
+      for (int m = 1; m < kChienCoefLong; ++m) {
         const int e = ((255 - m) * 32 * seg) % 255;
         for (int b = 0; b < 8; ++b) {
           uint32_t r = 0;
@@ -511,26 +512,26 @@ __constant__ constexpr ChienAdvance kChienAdvance{};
 // TWO wavefronts of the same (64 groups, segment): half 0 carries T_0 .. T_8, half 1 carries T_9 .. T_16; each forms
 // its partial sums for two positions, one of them (taking turns) hands its 16 words per lane to the other through
 // LDS, and that one tests the sums and writes the mask words.  Four wavefronts per SIMD.
-template <int M0, int... M>
-__device__ __forceinline__ void chien_step(uint32_t (&T)[9][8], std::integer_sequence<int, M...>) {
+template <int M0, int NT, int... M>
+__device__ __forceinline__ void chien_step(uint32_t (&T)[NT][8], std::integer_sequence<int, M...>) {
   const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ((M0 + M == 0 ? (void)0 : horner<(255 - (M0 + M)) % 255>(T[M], zero)), ...);
 }
-// H = 0: coefficients 0 .. 8, H = 1: coefficients 9 .. 16 (T[8] unused)
-template <int H>
+// NCOEF = 17: H = 0 carries coefficients 0 .. 8, H = 1 coefficients 9 .. 16 (its last T unused); NCOEF = 25: 0 .. 12 / 13 .. 24
+template <int H, int NCOEF>
 __device__ __forceinline__ void chien_half(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, uint32_t *__restrict__ xch,
                                            unsigned long long blk, int seg, unsigned long long G) {
-  constexpr int M0 = H ? 9 : 0, MC = H ? 8 : 9, PB = 2;  // PB positions per batch (four: spills at 128 registers)
+  constexpr int NT = (NCOEF + 1) / 2, M0 = H ? NT : 0, MC = H ? NCOEF / 2 : NT, PB = 2;  // PB positions per batch (four: spills)
   const int lane = threadIdx.x & 63;
   const unsigned long long g = blk * 64 + lane;
   const bool live = g < G;
-  uint32_t T[9][8];
+  uint32_t T[NT][8];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < NT; ++k) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) T[k][b] = 0;
     if (k < MC && live) {
-      const uint4 *src = lamp + ((blk * kChienCoef + (M0 + k)) * 64 + lane) * 2;
+      const uint4 *src = lamp + ((blk * NCOEF + (M0 + k)) * 64 + lane) * 2;
       const uint4 a = src[0], c = src[1];
       T[k][0] = a.x, T[k][1] = a.y, T[k][2] = a.z, T[k][3] = a.w;
       T[k][4] = c.x, T[k][5] = c.y, T[k][6] = c.z, T[k][7] = c.w;
@@ -565,7 +566,7 @@ __device__ __forceinline__ void chien_half(const uint4 *__restrict__ lamp, uint2
         for (int k = 1; k < MC; ++k) sum ^= T[k][b];
         part[u][b] = sum;
       }
-      chien_step<M0>(T, Mine());
+      chien_step<M0, NT>(T, Mine());
       // keep the steps apart: flattened over several steps the XOR networks grow into sums over every earlier plane
 #pragma unroll
       for (int k = 0; k < MC; ++k)
@@ -596,14 +597,15 @@ __device__ __forceinline__ void chien_half(const uint4 *__restrict__ lamp, uint2
 }
 // workgroup = 64 groups x 2 segments x 2 coefficient halves; a lane writes the 128-byte line of masks[group][256] of its
 // segment, 8 bytes at a time
-__global__ void __launch_bounds__(256, 4)
+template <int NCOEF>
+__global__ void __launch_bounds__(256, NCOEF <= 17 ? 4 : 2)
 bitslice_chien_kernel(const uint4 *__restrict__ lamp, uint2 *__restrict__ masks, unsigned long long G) {
   __shared__ uint32_t xch_all[2][2 * 16 * 64];  // [segment of the workgroup][buffer][word][lane]: 16 KB
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long blk = blockIdx.x >> 2;
   const int sg = wid >> 1, seg = static_cast<int>(blockIdx.x & 3) * 2 + sg;
-  if (wid & 1) chien_half<1>(lamp, masks, xch_all[sg], blk, seg, G);
-  else chien_half<0>(lamp, masks, xch_all[sg], blk, seg, G);
+  if (wid & 1) chien_half<1, NCOEF>(lamp, masks, xch_all[sg], blk, seg, G);
+  else chien_half<0, NCOEF>(lamp, masks, xch_all[sg], blk, seg, G);
 }
 
 // masks[group][256] (word = position, bit = frame in plane order) -> rootsT[group][8][32] (word = frame in plane order,
@@ -691,11 +693,16 @@ int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_
   return CC_OK;
 }
 
-// lamp: G64 * 17 * 32 bytes (chunk_bm_kernel), masks: G64 * 256 words
-int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, hipStream_t stream) {
+// lamp: G64 * 17 (25 with long locators) * 32 bytes (chunk_bm kernels), masks: G64 * 256 words
+int launch_bitslice_chien(const void *d_lamp, void *d_masks, size_t B, bool long_locators, hipStream_t stream) {
   const unsigned long long G = (B + 31) / 32;
-  hipLaunchKernelGGL(bitslice_chien_kernel, dim3(static_cast<unsigned>(4 * ((G + 63) / 64))), dim3(256), 0, stream,
-                     static_cast<const uint4 *>(d_lamp), static_cast<uint2 *>(d_masks), G);
+  const dim3 grid(static_cast<unsigned>(4 * ((G + 63) / 64)));
+  if (long_locators)
+    hipLaunchKernelGGL((bitslice_chien_kernel<kChienCoefLong>), grid, dim3(256), 0, stream, static_cast<const uint4 *>(d_lamp),
+                       static_cast<uint2 *>(d_masks), G);
+  else
+    hipLaunchKernelGGL((bitslice_chien_kernel<kChienCoef>), grid, dim3(256), 0, stream, static_cast<const uint4 *>(d_lamp),
+                       static_cast<uint2 *>(d_masks), G);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice chien kernel launch");
   return CC_OK;
