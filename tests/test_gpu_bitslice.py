@@ -210,3 +210,52 @@ def test_erasure_paths_agree():
         outs.append(lines)
     assert outs[0] == outs[1], "\n".join(a + "\n" + b for a, b in zip(*outs) if a != b)
     assert any("erasures 0 " not in l for l in outs[0]) and any("recheck 0 " not in l for l in outs[0])
+
+
+@pytest.mark.parametrize("alg", [BM, EUKLID])
+def test_erasure_calls_without_count_and_status_buffers(alg):
+    """nerr / status may be NULL (channelcoding_amd.h): the erasure chain -- and the Euklid tag's second stage, which
+    reads the status the chain left -- must return the same words without them."""
+    import ctypes as C
+
+    import torch
+    from channelcoding_amd import capi
+    o = Oracle(RS, 8, 16)
+    code = make(RS, 16, alg)
+    rng = np.random.default_rng(900 + alg)
+    frames = 20000
+    base = o.encode(rng.integers(0, 256, (250, o.l)).astype(np.uint8))
+    rx, ers = base.copy(), []
+    for f in range(250):
+        ne = int(rng.integers(0, 34))
+        er = sorted(rng.choice(o.n, ne, replace=False).tolist())
+        for e in er:
+            rx[f, e] = 0
+        free = np.setdiff1d(np.arange(o.n), er)
+        for p in rng.choice(free, int(rng.integers(0, max(1, (32 - ne) // 2 + 2))), replace=False):
+            rx[f, p] ^= int(rng.integers(1, 256))
+        ers.append(er)
+    reps = frames // 250
+    rxb = np.tile(rx, (reps, 1))
+    pos = np.array([e for _ in range(reps) for er in ers for e in er], np.uint16)
+    cnt = np.array([len(er) for _ in range(reps) for er in ers], np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+    lib = capi.lib()
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    d_in = torch.from_numpy(rxb).cuda()
+    d_pos = torch.from_numpy(pos.view(np.int16)).cuda()
+    d_off = torch.from_numpy(off.view(np.int32)).cuda()
+    outs = [torch.empty_like(d_in) for _ in range(2)]
+    ne_ = torch.empty(frames, dtype=torch.int32, device="cuda")
+    st_ = torch.empty(frames, dtype=torch.int32, device="cuda")
+    sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cc_correct_hard_batch_dev(code._h, vp(d_in), vp(d_pos), vp(d_off), vp(outs[0]), vp(ne_), vp(st_), frames, sh) == 0
+    assert lib.cc_correct_hard_batch_dev(code._h, vp(d_in), vp(d_pos), vp(d_off), vp(outs[1]), None, None, frames, sh) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    head = dict(out=outs[0][:250].cpu().numpy(), nerr=ne_[:250].cpu().numpy(), status=st_[:250].cpu().numpy())
+    for f in range(250):
+        out, nerr, st, ub = o.correct_hard(alg, rx[f], ers[f])
+        assert (head["status"][f] == 0) == (st[0] == 0), (alg, f, len(ers[f]))
+        if st[0] == 0:
+            assert np.array_equal(head["out"][f], out[0]) and head["nerr"][f] == nerr[0], (alg, f)
