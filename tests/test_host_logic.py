@@ -243,6 +243,8 @@ def test_dispatched_kernels_do_not_spill():
     # keep q instead of r since round 3, profiles/r03_experiments.md E38)
     allowed = {("geo_g255_32", v): 2 for v in (16, 17, 18, 19, 20, 21)}
     allowed[("geo_g63_24", 19)] = 9  # SCMS1 with bit words at three waves per SIMD: faster than the q-only form all the same (E38)
+    # BCH(127,99), 196 message registers: two waves per SIMD with these spills beat one wave without (MS 43.9 -> 53.1 M, E41)
+    allowed.update({("geo_g127_28", v): 38 for v in (16, 17, 18, 19, 20, 21)})
     seen = 0
     for path in objs:
         name = __import__("re").sub(r"(_p\d+)?\.o$", "", os.path.basename(path))  # geo_NAME_p<part>.o -> geo_NAME
