@@ -79,6 +79,9 @@ random_bits_kernel(uint8_t *__restrict__ msg, int l, int group_log2, unsigned lo
 
 // G = lanes per frame (power of two >= ceil(n / 4)), lane q of a group draws the four values 4q .. 4q + 3 of its
 // frame from Philox counter (frame, q): no division by n anywhere, 16-byte stores except for a ragged tail.
+// HARD: the hard decision of y (bit = y < 0, cyclic.h:163-173) as bytes instead of y itself -- what a hard-decision decoder
+// takes from the channel: a quarter of the bytes written here and read by the syndrome kernel
+template <bool HARD>
 __global__ void __launch_bounds__(256)
 awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, int group_log2,
             unsigned long long first_frame, unsigned long long frames, float sigma, uint32_t k0, uint32_t k1,
@@ -106,17 +109,24 @@ awgn_kernel(float *__restrict__ llr, const uint8_t *__restrict__ sent, int n, in
         x[s] = (one ? -1.0f : 1.0f) + sigma * z[s];  // BPSK 0 -> +1
         cherr += (x[s] < 0.0f) != one;
       }
-      // frames are n floats apart, so dst is 4-byte aligned only: four dword stores the compiler may merge
-      dst[0] = x[0];
-      dst[1] = x[1];
-      dst[2] = x[2];
-      dst[3] = x[3];
+      if (HARD) {
+        uint8_t *hd = reinterpret_cast<uint8_t *>(llr) + f * n + 4 * qd;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) hd[s] = x[s] < 0.0f ? 1 : 0;
+      } else {
+        // frames are n floats apart, so dst is 4-byte aligned only: four dword stores the compiler may merge
+        dst[0] = x[0];
+        dst[1] = x[1];
+        dst[2] = x[2];
+        dst[3] = x[3];
+      }
     } else {
       for (int s = 0; 4 * qd + s < n; ++s) {
         const bool one = src && src[s];
         const float x = (one ? -1.0f : 1.0f) + sigma * z[s];
         cherr += (x < 0.0f) != one;
-        dst[s] = x;
+        if (HARD) reinterpret_cast<uint8_t *>(llr)[f * n + 4 * qd + s] = x < 0.0f ? 1 : 0;
+        else dst[s] = x;
       }
     }
   }
@@ -413,7 +423,7 @@ static bool mc_precheck_pays(const cc_code *code, double ebno_db) {
 // writes y (and the transmitted words when d_sent != nullptr) for frames [first, first + frames)
 int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, size_t frames,
                 int random_codewords, float *d_llr, uint8_t *d_sent, uint8_t *d_msg_scratch, hipStream_t stream,
-                unsigned long long *d_counters = nullptr) {
+                unsigned long long *d_counters = nullptr, bool hard_bytes = false) {
   if (frames == 0) return CC_OK;
   const int n = static_cast<int>(code->tab.n);
   const float sigma = static_cast<float>(cc_sigma(code, ebno_db));  // normal_distribution<float>(1.0, float(sigma))
@@ -429,9 +439,14 @@ int launch_awgn(const cc_code *code, double ebno_db, uint64_t seed, uint64_t fir
   int group_log2 = 0;
   while ((4 << group_log2) < n) ++group_log2;
   const unsigned long long items = static_cast<unsigned long long>(frames) << group_log2;
-  hipLaunchKernelGGL(awgn_kernel, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n, group_log2,
-                     static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
-                     k1, d_counters);
+  if (hard_bytes)
+    hipLaunchKernelGGL(awgn_kernel<true>, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n, group_log2,
+                       static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
+                       k1, d_counters);
+  else
+    hipLaunchKernelGGL(awgn_kernel<false>, dim3(grid_for(code, items)), dim3(256), 0, stream, d_llr, sent, n, group_log2,
+                       static_cast<unsigned long long>(first_frame), static_cast<unsigned long long>(frames), sigma, k0,
+                       k1, d_counters);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "awgn kernel launch");
   return CC_OK;
@@ -482,13 +497,14 @@ int mc_run(cc_code *code, double ebno_db, uint64_t seed, uint64_t first_frame, s
       if (e != hipSuccess) return hip_fail(e, "count kernel launch");
       continue;
     }
+    // (a hard-decision decoder takes bits from the channel: the hard decisions as bytes in the same buffer)
     rc = launch_awgn(code, ebno_db, seed, first_frame + done, m, random_codewords, w.llr, sent, w.msg, stream,
-                     reinterpret_cast<unsigned long long *>(d_counters));
+                     reinterpret_cast<unsigned long long *>(d_counters), !code->soft);
     if (rc != CC_OK) return rc;
     if (code->soft)
       rc = launch_minsum(code, w.llr, nullptr, nullptr, w.hard, nullptr, w.iters, w.status, m, stream);
     else
-      rc = launch_algebraic(code, true, w.llr, nullptr, nullptr, w.hard, w.nerr, w.status, m, stream);
+      rc = launch_algebraic(code, false, w.llr, nullptr, nullptr, w.hard, w.nerr, w.status, m, stream);
     if (rc != CC_OK) return rc;
     const unsigned long long blocks = (m + 15) / 16;
     const unsigned long long max_grid = static_cast<unsigned long long>(code->num_cus) * 8;
