@@ -7,12 +7,10 @@
 // on average 25.8 XORs per Horner step for j = 1 .. 32 including the addition of the next symbol: 0.8
 // instructions per symbol-multiply instead of a logarithm add, a wrap, a table gather and an XOR per symbol.
 //
-//   bitslice_planes_kernel     bytes [frame][n] -> planes [block of 64 groups][p][group][8] (group = 32 frames;
-//                              2 KB per position and block, read by one wavefront at a time), and the copy of the
-//                              received words into the output buffer (the corrector only patches the errors);
-//                              wavefront = group, lane = four adjacent positions
-//   bitslice_syndrome_kernel   lane = group, wavefront w of a workgroup = syndromes 8w+1 .. 8w+8 of the same 64
-//                              groups; the result goes back to bytes as [block][j][group][32]
+//   bitslice_fused_syndrome_kernel   bytes [frame][n] -> planes in LDS -> syndromes, back to bytes as
+//                                    [block of 64 groups][j][group][32] (group = 32 frames), and the copy of the received
+//                                    words into the output buffer (the corrector only patches the errors); RAW: the
+//                                    encoder's evaluations, left on planes
 //
 // The byte <-> plane transposition is three butterfly stages on eight registers whose word k carries the
 // frames {k, 8+k, 16+k, 24+k} of the group, so no bit permutation is left over; the consumer
@@ -32,149 +30,9 @@ namespace {
 
 using namespace bitplane;
 
-// One wavefront per group of 32 frames.  Lane l owns the four positions q .. q+3, q = min(4 l, n - 4): one (unaligned)
-// dword per frame and lane instead of four byte loads -- the byte form was bound by the rate of the memory
-// instructions, 64 B each.  The last lane re-does position n - 4 .. 4 l - 1 of its neighbour (same values).
-template <bool FLOAT_IN>
-__global__ void __launch_bounds__(256)
-bitslice_planes_kernel(const void *__restrict__ in_raw, uint8_t *__restrict__ out, uint4 *__restrict__ planes,
-                       unsigned long long B, unsigned long long G, int n_in, int n, int off) {
-  const int lane = threadIdx.x & 63;
-  // (made wave-uniform for the compiler: frame addresses become scalar bases plus one 32-bit lane offset)
-  const unsigned long long wave =
-      static_cast<unsigned long long>(blockIdx.x) * 4 + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-  const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * 4;
-  // decoding: n_in = n, off = 0.  Encoding: the n_in message symbols of a frame go to the positions off .. n - 1 of
-  // its codeword (cyclic.h:29-40) and of the planes; the parity positions below off are filled in later.
-  if (4 * lane >= n_in + 3) return;
-  const int q = 4 * lane < n_in - 4 ? 4 * lane : n_in - 4;
-  for (unsigned long long g = wave; g < G; g += nwaves) {
-    const unsigned long long f0 = g * 32;
-    const int frames = static_cast<int>((B - f0) < 32ull ? (B - f0) : 32ull);
-    uint32_t v[32];
-    auto fetch = [&](int f) -> uint32_t {
-      const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n_in) + q;
-      if (FLOAT_IN) {  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
-        const float *x = static_cast<const float *>(in_raw) + at;
-        return (x[0] < 0.0f ? 1u : 0u) | (x[1] < 0.0f ? 0x100u : 0u) | (x[2] < 0.0f ? 0x10000u : 0u) |
-               (x[3] < 0.0f ? 0x1000000u : 0u);
-      }
-      uint32_t r;
-      __builtin_memcpy(&r, static_cast<const uint8_t *>(in_raw) + at, 4);
-      return r;
-    };
-    if (frames == 32) {
-#pragma unroll
-      for (int f = 0; f < 32; ++f) v[f] = fetch(f);
-#pragma unroll
-      for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
-    } else {
-#pragma unroll
-      for (int f = 0; f < 32; ++f) {
-        v[f] = 0;
-        if (f < frames) {
-          v[f] = fetch(f);
-          __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t w[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {  // word k = byte i of the frames {k, 8+k, 16+k, 24+k}
-        const uint32_t sel = 0x0c0c0000u | static_cast<uint32_t>((4 + i) << 8) | static_cast<uint32_t>(i);
-        const uint32_t lo = __builtin_amdgcn_perm(v[8 + k], v[k], sel), hi = __builtin_amdgcn_perm(v[24 + k], v[16 + k], sel);
-        w[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-      }
-      butterfly(w);  // word b, bit f = bit b of the symbol of frame f
-      uint4 *dst = planes + (((g >> 6) * n + (off + q + i)) * 64 + (g & 63)) * 2;
-      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-  }
-}
-
-// syndromes of the roots alpha^(J0+1) .. alpha^(J0+8).  Positions below p_lo count as zero (the parity positions of
-// a word that is being encoded); RAW keeps the result on planes ([block][j][group][8]) for the interpolation.
-template <int J0, bool RAW>
-__device__ __forceinline__ void syndromes8(const uint4 *__restrict__ planes, uint8_t *__restrict__ synd,
-                                           unsigned long long g, int n, int t2, int p_lo) {
-  uint32_t s[8][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) s[j][b] = 0;
-  const uint4 *src = planes + ((g >> 6) * n * 64 + (g & 63)) * 2;
-  const unsigned long long pitch = 128;
-  auto all8 = [&](const uint32_t (&r)[8]) {
-    horner<J0 + 1>(s[0], r);
-    horner<J0 + 2>(s[1], r);
-    horner<J0 + 3>(s[2], r);
-    horner<J0 + 4>(s[3], r);
-    horner<J0 + 5>(s[4], r);
-    horner<J0 + 6>(s[5], r);
-    horner<J0 + 7>(s[6], r);
-    horner<J0 + 8>(s[7], r);
-  };
-  // two positions per trip: the planes written by the first step are the operands of the second, so the in-place
-  // update needs no register copies
-  int p = n - 1;
-  uint4 a0 = src[static_cast<unsigned long long>(p) * pitch], b0 = src[static_cast<unsigned long long>(p) * pitch + 1];
-  if (((n - p_lo) & 1) != 0) {
-    const uint32_t r[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
-    all8(r);
-    --p;
-    if (p >= p_lo) {
-      a0 = src[static_cast<unsigned long long>(p) * pitch];
-      b0 = src[static_cast<unsigned long long>(p) * pitch + 1];
-    }
-  }
-  for (; p >= p_lo + 1; p -= 2) {
-    const uint4 a1 = src[static_cast<unsigned long long>(p - 1) * pitch], b1 = src[static_cast<unsigned long long>(p - 1) * pitch + 1];
-    const uint32_t r0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
-    const uint32_t r1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
-    const int pn = p >= p_lo + 2 ? p - 2 : p_lo;  // the last trip re-reads a position (no branch around the prefetch)
-    a0 = src[static_cast<unsigned long long>(pn) * pitch];
-    b0 = src[static_cast<unsigned long long>(pn) * pitch + 1];
-    all8(r0);
-    all8(r1);
-  }
-  if (RAW) {
-    const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int z = 0; z < p_lo; z += 2) {  // times x^p_lo (p_lo is even)
-      all8(zero);
-      all8(zero);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (J0 + j >= t2) break;
-    if (!RAW) butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
-    uint4 *dst = reinterpret_cast<uint4 *>(synd + (((g >> 6) * t2 + (J0 + j)) * 64 + (g & 63)) * 32);
-    dst[0] = make_uint4(s[j][0], s[j][1], s[j][2], s[j][3]);
-    dst[1] = make_uint4(s[j][4], s[j][5], s[j][6], s[j][7]);
-  }
-}
-
-template <bool RAW>
-__global__ void __launch_bounds__(256)
-bitslice_syndrome_kernel(const uint4 *__restrict__ planes, uint8_t *__restrict__ synd, unsigned long long G, int n, int t2,
-                         int p_lo) {
-  const int wid = threadIdx.x >> 6;
-  const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * 64 + (threadIdx.x & 63);
-  if (g >= G) return;
-  switch (wid) {
-    case 0: syndromes8<0, RAW>(planes, synd, g, n, t2, p_lo); break;
-    case 1: syndromes8<8, RAW>(planes, synd, g, n, t2, p_lo); break;
-    case 2: syndromes8<16, RAW>(planes, synd, g, n, t2, p_lo); break;
-    default: syndromes8<24, RAW>(planes, synd, g, n, t2, p_lo); break;
-  }
-}
-
-// ---------------- decoding: bytes -> planes in LDS -> syndromes, one kernel ----------------
-// The two kernels above exchange the planes through HBM (255 B written + 255 B read per frame) and the syndrome kernel
-// can only fill 2 wavefronts per SIMD (a lane owns a whole group: 2^20 frames are 2048 wavefronts).  Fused form: a
+// ---------------- bytes -> planes in LDS -> syndromes, one kernel ----------------
+// Rounds 1-2 had two kernels that exchanged the planes through HBM (255 B written + 255 B read per frame), and the
+// syndrome kernel could only fill 2 wavefronts per SIMD (a lane owned a whole group: 2^20 frames were 2048 wavefronts).  Now: a
 // workgroup of eight wavefronts takes 8 groups (256 frames, 65 280 contiguous bytes); wavefront w transposes group w
 // into LDS, then -- lane = (group, segment of 32 positions), wavefront w = syndromes 4w+1 .. 4w+4 -- every lane runs the
 // Horner chains of ITS segment, part_s = sum_i b[32 s + i] alpha^(j i), and the eight segments of a group are folded as
@@ -207,7 +65,8 @@ template <int J> __device__ __forceinline__ void fold_all(uint32_t (&part)[8]) {
 }
 
 // syndromes J0+1 .. J0+4 of the workgroup's groups: lane = (group lane >> 3, segment lane & 7)
-template <int J0>
+// RAW keeps the result on planes ([block][j][group][8]) for the encoder's interpolation
+template <int J0, bool RAW>
 __device__ __forceinline__ void fused_syndromes4(const uint4 *__restrict__ lds, uint8_t *__restrict__ synd,
                                                  unsigned long long group0, unsigned long long G, int t2) {
   const int lane = threadIdx.x & 63, g = lane >> 3, seg = lane & 7;
@@ -241,17 +100,20 @@ __device__ __forceinline__ void fused_syndromes4(const uint4 *__restrict__ lds, 
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (J0 + j >= t2) break;
-    butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
+    if (!RAW) butterfly(s[j]);  // word k = bytes of the frames {k, 8+k, 16+k, 24+k}
     uint4 *dst = reinterpret_cast<uint4 *>(synd + (((gg >> 6) * t2 + (J0 + j)) * 64 + (gg & 63)) * 32);
     dst[0] = make_uint4(s[j][0], s[j][1], s[j][2], s[j][3]);
     dst[1] = make_uint4(s[j][4], s[j][5], s[j][6], s[j][7]);
   }
 }
 
-template <bool FLOAT_IN>
+// decoding: n_in = n, off = 0.  Encoding (RAW): the n_in message symbols of a frame go to the positions off .. n - 1 of
+// its codeword (cyclic.h:29-40) -- in `out` and on the planes, whose positions below off stay zero -- and the result is
+// (a x^k)(alpha^j) on planes for bitslice_parity_kernel.
+template <bool FLOAT_IN, bool RAW>
 __global__ void __launch_bounds__(kFusedThreads, 4)
 bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__restrict__ synd, unsigned long long B,
-                               unsigned long long G, int n, int t2) {
+                               unsigned long long G, int n, int t2, int n_in, int off) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fused_smem[];
   uint4 *lds = reinterpret_cast<uint4 *>(fused_smem);
 #ifdef CC_AMD_EXPERIMENTS  // CC_EXP_FUSED bits (in n >> 16): 1 no copy of the words, 2 no syndromes (phase timing, E27), 4 + 16 k: stagger (E33)
@@ -267,19 +129,20 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
 #endif
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long group0 = static_cast<unsigned long long>(blockIdx.x) * kFusedGroups;
-  // positions n .. 255 do not exist: zero planes (n = 255: one position)
-  for (int k = threadIdx.x; k < (256 - n) * 16; k += kFusedThreads) {
-    const int p = n + (k >> 4), i = p & 31;
+  // positions n .. 255 do not exist, positions below off carry nothing yet (the parity symbols): zero planes
+  for (int k = threadIdx.x; k < (256 - n + off) * 16; k += kFusedThreads) {
+    const int z = k >> 4, p = z < off ? z : n + (z - off), i = p & 31;
     lds[(i * 2 + ((k >> 3) & 1)) * 64 + 8 * (p >> 5) + (k & 7)] = make_uint4(0, 0, 0, 0);
   }
-  {  // ---- wavefront = group: lane l owns the four positions q .. q+3, q = min(4 l, n - 4) (see bitslice_planes_kernel) ----
+  {  // ---- wavefront = group: lane l owns the four input symbols q .. q+3, q = min(4 l, n_in - 4): one (unaligned) dword per
+     //      frame and lane; the last lane re-does symbols of its neighbour (same values) ----
     const unsigned long long g = group0 + wid, f0 = g * 32;
     const int frames = g >= G ? 0 : static_cast<int>((B - f0) < 32ull ? (B - f0) : 32ull);
-    const int q = 4 * lane < n - 4 ? 4 * lane : n - 4;
-    if (4 * lane < n + 3) {
+    const int q = 4 * lane < n_in - 4 ? 4 * lane : n_in - 4;
+    if (4 * lane < n_in + 3) {
       uint32_t v[32];
       auto fetch = [&](int f) -> uint32_t {
-        const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n) + q;
+        const unsigned long long at = (f0 + f) * static_cast<unsigned long long>(n_in) + q;
         if (FLOAT_IN) {  // hard decision of a signed sequence: cyclic.h:163-173, codes.h:43-52
           const float *x = static_cast<const float *>(in_raw) + at;
           return (x[0] < 0.0f ? 1u : 0u) | (x[1] < 0.0f ? 0x100u : 0u) | (x[2] < 0.0f ? 0x10000u : 0u) |
@@ -294,7 +157,7 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
         for (int f = 0; f < 32; ++f) v[f] = fetch(f);
         if (copy) {
 #pragma unroll
-          for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+          for (int f = 0; f < 32; ++f) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
         }
       } else {
 #pragma unroll
@@ -302,7 +165,7 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
           v[f] = 0;
           if (f < frames) {
             v[f] = fetch(f);
-            if (copy) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + q, &v[f], 4);
+            if (copy) __builtin_memcpy(out + (f0 + f) * static_cast<unsigned long long>(n) + off + q, &v[f], 4);
           }
         }
       }
@@ -316,7 +179,7 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
           w[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
         }
         butterfly(w);  // word b, bit f = bit b of the symbol of frame f
-        const int p = q + c, i = p & 31;
+        const int p = off + q + c, i = p & 31;
         uint4 *dst = lds + (i * 2) * 64 + 8 * (p >> 5) + (wid ^ (i >> 2));
         dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
         dst[64] = make_uint4(w[4], w[5], w[6], w[7]);
@@ -326,14 +189,14 @@ bitslice_fused_syndrome_kernel(const void *in_raw, uint8_t *out, uint8_t *__rest
   __syncthreads();
   if (4 * wid >= t2 || (xs & 2)) return;
   switch (wid) {
-    case 0: fused_syndromes4<0>(lds, synd, group0, G, t2); break;
-    case 1: fused_syndromes4<4>(lds, synd, group0, G, t2); break;
-    case 2: fused_syndromes4<8>(lds, synd, group0, G, t2); break;
-    case 3: fused_syndromes4<12>(lds, synd, group0, G, t2); break;
-    case 4: fused_syndromes4<16>(lds, synd, group0, G, t2); break;
-    case 5: fused_syndromes4<20>(lds, synd, group0, G, t2); break;
-    case 6: fused_syndromes4<24>(lds, synd, group0, G, t2); break;
-    default: fused_syndromes4<28>(lds, synd, group0, G, t2); break;
+    case 0: fused_syndromes4<0, RAW>(lds, synd, group0, G, t2); break;
+    case 1: fused_syndromes4<4, RAW>(lds, synd, group0, G, t2); break;
+    case 2: fused_syndromes4<8, RAW>(lds, synd, group0, G, t2); break;
+    case 3: fused_syndromes4<12, RAW>(lds, synd, group0, G, t2); break;
+    case 4: fused_syndromes4<16, RAW>(lds, synd, group0, G, t2); break;
+    case 5: fused_syndromes4<20, RAW>(lds, synd, group0, G, t2); break;
+    case 6: fused_syndromes4<24, RAW>(lds, synd, group0, G, t2); break;
+    default: fused_syndromes4<28, RAW>(lds, synd, group0, G, t2); break;
   }
 }
 
@@ -676,17 +539,17 @@ int launch_bitslice_syndromes(const cc_code *code, bool float_in, const void *d_
   const unsigned grid = static_cast<unsigned>((G + kFusedGroups - 1) / kFusedGroups);
   hipError_t e = hipSuccess;
   if (float_in) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsBytes));
     if (e == hipSuccess)
-      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<true>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream, d_in,
-                         d_out, d_synd, Bq, G, n, t2);
+      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<true, false>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream,
+                         d_in, d_out, d_synd, Bq, G, n, t2, n & 0xFFFF, 0);
   } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsBytes));
     if (e == hipSuccess)
-      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<false>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream, d_in,
-                         d_out, d_synd, Bq, G, n, t2);
+      hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<false, false>), dim3(grid), dim3(kFusedThreads), kFusedLdsBytes, stream,
+                         d_in, d_out, d_synd, Bq, G, n, t2, n & 0xFFFF, 0);
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "bitslice fused syndrome kernel launch");
@@ -729,21 +592,18 @@ int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d
   const int n = static_cast<int>(code->tab.n), k = static_cast<int>(code->tab.k), l = static_cast<int>(code->tab.l);
   const unsigned long long G = (B + 31) / 32, Bq = B;
   const size_t G64 = static_cast<size_t>((G + 63) / 64) * 64;
-  const size_t plane_bytes = G64 * n * 32, eval_bytes = G64 * k * 32;
-  uint8_t *ws = nullptr;  // stream-ordered and pool-cached
-  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&ws), plane_bytes + eval_bytes, stream));
-  uint8_t *d_eval = ws + plane_bytes;
-  const unsigned long long want = (G + 3) / 4, cap = static_cast<unsigned long long>(code->num_cus) * 32;
-  const int grid = static_cast<int>(want < cap ? want : cap);
-  hipLaunchKernelGGL((bitslice_planes_kernel<false>), dim3(grid), dim3(256), 0, stream, static_cast<const void *>(d_msg), d_cw,
-                     reinterpret_cast<uint4 *>(ws), Bq, G, l, n, k);
-  hipError_t e = hipGetLastError();
+  const size_t eval_bytes = G64 * k * 32;
+  uint8_t *d_eval = nullptr;  // stream-ordered and pool-cached
+  CC_HIP_TRY(workspace_alloc(code, reinterpret_cast<void **>(&d_eval), eval_bytes, stream));
+  // message -> codeword body and planes in LDS -> evaluations at the 2t roots (the fused kernel of the decoder, RAW)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&bitslice_fused_syndrome_kernel<false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsBytes));
   if (e == hipSuccess) {
-    hipLaunchKernelGGL((bitslice_syndrome_kernel<true>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(64 * (k / 8)), 0,
-                       stream, reinterpret_cast<const uint4 *>(ws), d_eval, G, n, k, k);
+    hipLaunchKernelGGL((bitslice_fused_syndrome_kernel<false, true>), dim3(static_cast<unsigned>((G + kFusedGroups - 1) / kFusedGroups)),
+                       dim3(kFusedThreads), kFusedLdsBytes, stream, static_cast<const void *>(d_msg), d_cw, d_eval, Bq, G, n, k, l, k);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) {
+  if (e == hipSuccess) {  // interpolation of the remainder
     if (k == 32)
       hipLaunchKernelGGL((bitslice_parity_kernel<32>), dim3(static_cast<unsigned>((G + 63) / 64)), dim3(256), 0, stream,
                          reinterpret_cast<const uint4 *>(d_eval), d_cw, Bq, G, n);
@@ -752,7 +612,7 @@ int launch_bitslice_encode(const cc_code *code, const uint8_t *d_msg, uint8_t *d
                          reinterpret_cast<const uint4 *>(d_eval), d_cw, Bq, G, n);
     e = hipGetLastError();
   }
-  (void)hipFreeAsync(ws, stream);
+  (void)hipFreeAsync(d_eval, stream);
   if (e != hipSuccess) return hip_fail(e, "bitslice encode kernels launch");
   return CC_OK;
 }
