@@ -85,12 +85,12 @@ write = counter_sum("pmc_rs", "WRITE_SIZE", lambda n: True)
 med = lambda v: sorted(v)[len(v) // 2]  # (the one encode call that makes the codewords uses two of the kernels too)
 per_kernel = {k: (med(v), med(write.get(k, [0]))) for k, v in fetch.items()}
 dec = {k: v for k, v in per_kernel.items()
-       if "parity_kernel" not in k and "bitslice_syndrome_kernel<" not in k and "bitslice_planes_kernel" not in k}
+       if "parity_kernel" not in k and "bitslice_fused_syndrome_kernel<false, true>" not in k}  # (the encoder's two kernels)
 total = sum(2 * a + b for a, b in dec.values()) * 1024
 json.dump({"workload": "rs255_223_bm_2^20", "round": 3, "traffic_bytes_per_launch": int(total),
            "traffic_bytes_per_frame": round(total / (1 << 20), 1), "algorithmic_bytes_per_frame": 518,
            "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section) + WRITE_SIZE; decode kernels only "
-                         "(bitslice_planes / bitslice_syndrome<true> / bitslice_parity belong to the encoder rs_bench.py also runs)",
+                         "(bitslice_fused_syndrome<false, RAW> / bitslice_parity belong to the encoder rs_bench.py also runs)",
            "kernels_KB_fetch_write": {k.replace("ccamd::(anonymous namespace)::", "")[:80]: [round(a), round(b)] for k, (a, b) in per_kernel.items()},
            "note": "per dispatch means; see r03_pmc_rs_decode.txt"}, open(os.path.join(DST, "traffic_rs.json"), "w"), indent=1)
 print("copied; traffic headline: %.4f GB per launch" % ((2 * fk + wk) * 1024 / 1e9))
