@@ -165,7 +165,8 @@ def secondary_workloads(torch, cc, capi, dev):
     ms_e = timed(lambda: lib.cc_correct_hard_batch_dev(rse._h, vp(rx), None, None, vp(outw), vp(ne), vp(st), B, sh))
     out["rs255_223_euklid_2^20"] = {"frames_per_s": B / (ms_e * 1e-3), "kernel_ms": ms_e,
                                     "all_frames_corrected": bool(torch.equal(outw, cw)) and int((st != 0).sum()) == 0}
-    enc_ms = timed(lambda: rs.encode_batch(cw[:, rs.k:].contiguous()))
+    msg_again = cw[:, rs.k:].contiguous()  # (the message, resident in HBM like every other input of the timed calls)
+    enc_ms = timed(lambda: rs.encode_batch(msg_again))
     out["rs255_223_encode_2^20"] = {"frames_per_s": B / (enc_ms * 1e-3), "kernel_ms": enc_ms}
     # errors and erasures (BM tag): 4 erased positions (zeroed, passed as CSR) + 0 .. 6 errors elsewhere per frame
     rho, maxe = 4, 6
