@@ -390,3 +390,25 @@ def test_minsum_large_batch_is_deterministic_and_exact(q, t, iters, log2b, ebno)
     ok = a["status"] == 0
     synd = (a["out"][ok].float() @ H.T) % 2
     assert ok.any() and not synd.any()
+
+
+def test_self_correcting_kernels_agree():
+    """profiles/tools/scms_soak.py: SCMS1 / SCMS2 x O1 / O2 on five geometries (the large ones keep q and work r out
+    again, E38) at 2 / 4.5 / 7 dB, 4096 seeded frames each, through the diagonal kernels and through the generic kernel
+    (CC_AMD_FORCE_GENERIC=1, a process each): the same hard decisions, iteration indices, status AND a-posteriori
+    values of every frame (SHA-256 over the four arrays)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "profiles", "tools", "scms_soak.py")
+    outs = []
+    for force in ("0", "1"):
+        r = subprocess.run([sys.executable, tool, "12"], env=dict(os.environ, CC_AMD_FORCE_GENERIC=force),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if "digest" in l]
+        assert len(lines) == 20 and all(" rc 0 " in l for l in lines), r.stdout[-2000:]
+        outs.append(lines)
+    assert all("minsum_diag_kernel" in l for l in outs[0]) and all("minsum_generic_kernel" in l for l in outs[1])
+    assert [l.split("digest")[1] for l in outs[0]] == [l.split("digest")[1] for l in outs[1]]
